@@ -1,0 +1,126 @@
+/* tgcn.h -- C ABI of the MI355X-native TextGCN hot path (libtgcn.so, HIP, gfx950 only).
+ *
+ * The reference has no FFI on this path: the arithmetic is PyG-1.6.3 `GCNConv`, reached from
+ * textgcn/lib/models.py:20 `layer(x, g.edge_index, g.edge_attr)` and differentiated by autograd at
+ * flat_amazon.py:105 `loss.backward()`.  This header is the boundary a maintainer binds instead
+ * (ctypes stub in INTEGRATION.md); each entry point names the reference step it replaces.
+ *
+ * Conventions
+ *   - plain C, `extern "C"`, no torch types; every data pointer is a DEVICE pointer on the plan's
+ *     device unless the comment says "host"; the caller owns every buffer it passes, the library
+ *     owns only the opaque plan (which holds its own copies of the graph).
+ *   - every function returns a status: 0 ok, <0 error (TGCN_E_*); tgcn_last_error() returns a
+ *     thread-local, human readable message for the last failing call on this thread.  Nothing
+ *     throws, nothing aborts the process.
+ *   - compute entry points (tgcn_spmm, tgcn_colsum, tgcn_xw_*) only ENQUEUE on the caller's stream,
+ *     never allocate and never synchronise (hipGraph-capturable).  tgcn_plan_create allocates and
+ *     synchronises `stream` (it is a one-off per graph).
+ *   - a plan is immutable after creation: safe to share between threads and streams as long as
+ *     concurrent calls use distinct workspaces.
+ *   - all arithmetic is IEEE fp32; results are bitwise reproducible run to run (no atomics).
+ */
+#ifndef TGCN_H_
+#define TGCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGCN_ABI_VERSION 1
+
+enum {
+    TGCN_OK = 0,
+    TGCN_E_INVALID = -1,   /* bad argument (null pointer, negative size, misaligned, F <= 0 ...) */
+    TGCN_E_RANGE = -2,     /* edge_index entry outside [0, n_nodes) or size beyond int32 limits   */
+    TGCN_E_HIP = -3,       /* a HIP runtime call failed (message carries hipGetErrorString)       */
+    TGCN_E_NOMEM = -4,     /* device or host allocation failed                                    */
+    TGCN_E_WORKSPACE = -5  /* workspace smaller than tgcn_*_workspace_bytes()                     */
+};
+
+typedef struct tgcn_plan tgcn_plan;   /* opaque */
+typedef void *tgcn_stream;            /* a hipStream_t; NULL = the null stream */
+
+int tgcn_abi_version(void);
+const char *tgcn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * tgcn_plan_create -- replaces PyG-1.6.3 gcn_norm (k1-k4 of SURVEY.md 2a), which the reference
+ * re-runs inside every GCNConv call (models.py:11-15 never pass cached=True): drop existing
+ * self-loops and re-append one per node (kept weight, else 1.0 -- add_remaining_self_loops, last
+ * duplicate wins), in-degree at the TARGET `dst = edge_index[1]` incl. the loop, d^-1/2 with inf->0,
+ * w_hat = d^-1/2[src] * w * d^-1/2[dst].  The result is kept as M (M[dst,src] = w_hat) in CSR sorted
+ * by (dst, src) -- and M^T likewise unless M == M^T bitwise -- with (col,val) interleaved as 8-byte
+ * pairs, plus the work-item partition the SpMM kernel walks.
+ *
+ *   n_nodes, n_edges      N and E = edge_index.shape[1]
+ *   src, src_stride       edge_index[0] (int64) and its element stride: the reference passes the
+ *   dst, dst_stride       non-contiguous view `coo.T` (text2graph.py:192), so strides are honoured
+ *   w                     edge_attr (fp32, contiguous) or NULL for all-ones
+ *   add_self_loops        GCNConv(add_self_loops=...) -- the reference always passes True
+ *   normalize             GCNConv(normalize=...)      -- the reference keeps the default True
+ *   row_begin, row_end    rows [row_begin,row_end) of M and of M^T that this plan will produce
+ *                         (1-D row partition across GPUs); 0, n_nodes for the whole graph.  The
+ *                         normalisation is always computed over the WHOLE edge list.
+ *   device                HIP device ordinal that owns every pointer
+ */
+int tgcn_plan_create(int64_t n_nodes, int64_t n_edges,
+                     const int64_t *src, int64_t src_stride,
+                     const int64_t *dst, int64_t dst_stride,
+                     const float *w, int add_self_loops, int normalize,
+                     int64_t row_begin, int64_t row_end,
+                     int device, tgcn_stream stream, tgcn_plan **out);
+
+int tgcn_plan_destroy(tgcn_plan *plan);
+
+/* tgcn_plan_query -- integers describing a plan (host pointer `out`). */
+enum {
+    TGCN_Q_N_NODES = 0,      /* N (= number of columns of M and M^T)                              */
+    TGCN_Q_N_ROWS = 1,       /* row_end - row_begin                                               */
+    TGCN_Q_NNZ = 2,          /* stored non-zeros of the forward block (E - loops_in_input + N ...) */
+    TGCN_Q_NNZ_T = 3,        /* ... of the transposed block                                       */
+    TGCN_Q_SYMMETRIC = 4,    /* 1 when M == M^T bitwise (the transposed copy is then not kept)    */
+    TGCN_Q_ITEMS = 5,        /* work items (wavefront tasks) of the forward block                 */
+    TGCN_Q_ITEMS_T = 6,
+    TGCN_Q_LONG_ROWS = 7,    /* rows split into segments (second-pass reduce), forward block      */
+    TGCN_Q_LONG_ROWS_T = 8,
+    TGCN_Q_SEGMENTS = 9,     /* carry rows written per SpMM, forward block                        */
+    TGCN_Q_SEGMENTS_T = 10,
+    TGCN_Q_DEVICE_BYTES = 11,/* device memory held by the plan                                    */
+    TGCN_Q_ROW_BEGIN = 12
+};
+int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out);
+
+/* tgcn_plan_export -- copy the stored CSR out (device buffers sized from tgcn_plan_query); any
+ * pointer may be NULL.  For tests and for the INTEGRATION.md binding; not on the hot path. */
+int tgcn_plan_export(const tgcn_plan *plan, int transpose, int32_t *rowptr /* n_rows+1 */,
+                     int32_t *col /* nnz */, float *val /* nnz */, tgcn_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * tgcn_spmm -- replaces MessagePassing.propagate + bias of GCNConv.forward (k6-k9: index_select,
+ * scale, scatter_add, `out += bias`) when transpose = 0, and its autograd (b1-b4: dXW = M^T dOut)
+ * when transpose = 1:
+ *       Y[r, 0:F] = sum_j  M(^T)[row_begin + r, j] * X[j, 0:F]  (+ bias[0:F])
+ *   X    [n_nodes, F] fp32, row stride ldx (elements)        -- the gathered operand
+ *   Y    [n_rows,  F] fp32, row stride ldy                    -- fully overwritten
+ *   bias [F] or NULL
+ * Fast path: F, ldx, ldy multiples of 4 and X, Y, bias 16-byte aligned; anything else takes the
+ * scalar-lane kernel (same results).  Nothing of size nnz x F is ever written.
+ */
+size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F);
+int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, int F,
+              const float *bias, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
+              tgcn_stream stream);
+
+/* tgcn_colsum -- replaces the autograd of `out += bias` (db = sum over rows of dOut).
+ *   G [n_rows, F] fp32 stride ldg -> out [F]. */
+size_t tgcn_colsum_workspace_bytes(int64_t n_rows, int F);
+int tgcn_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out, void *workspace,
+                size_t workspace_bytes, tgcn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGCN_H_ */

@@ -1,0 +1,56 @@
+"""Builds libtgcn.so (the HIP kernels + C ABI of include/tgcn.h) in-tree for gfx950.
+
+`hipcc` cross-compiles without a GPU, so this runs in the build container; the resulting
+pytextgcn_amd/lib/libtgcn.so is git-ignored but travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtgcn.so")
+SOURCES = ["spmm.hip", "colsum.hip", "plan.hip", "error.cpp"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(_ROOT, "include", "tgcn.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile if sources are newer than the library.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libtgcn.so cannot be built (ROCm toolchain required)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+    for s in SOURCES:
+        cmd += ["-x", "hip", os.path.join(CSRC, s)]
+    tmp = LIB_PATH + ".tmp%d" % os.getpid()
+    cmd += ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError("hipcc failed building libtgcn.so:\n" + res.stdout)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,126 @@
+"""GCNConv: drop-in for `torch_geometric.nn.GCNConv` (PyG 1.6.3) as PyTextGCN uses it.
+
+Call site replaced: textgcn/lib/models.py:20 `x = layer(x, g.edge_index, g.edge_attr)`, layers
+built at models.py:11,13,15 with `GCNConv(in, out, add_self_loops=True)`.  Same parameter names
+and layout as PyG 1.6.3 (`weight` (in, out) glorot-uniform, `bias` (out,) zeros), same semantics
+(norm -> x @ W -> propagate -> + bias), but the propagate step and its gradient are the HIP CSR
+SpMM of libtgcn.so and the normalisation is computed once per graph and cached.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .plan import GraphPlan, colsum, plan_for
+
+
+def _pad_cols(t: Tensor, width: int) -> Tensor:
+    if t.size(-1) == width:
+        return t
+    return torch.nn.functional.pad(t, (0, width - t.size(-1)))
+
+
+class _Propagate(torch.autograd.Function):
+    """out = M @ xw + bias;  d xw = M^T @ d out;  d bias = column sums of d out."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, xw: Tensor, bias: Optional[Tensor]):
+        F = xw.size(1)
+        F4 = (F + 3) & ~3                     # 16-byte rows keep the float4 kernel path
+        out = plan.spmm(_pad_cols(xw.detach(), F4),
+                        None if bias is None else _pad_cols(bias.detach(), F4))
+        ctx.plan = plan
+        ctx.F = F
+        ctx.has_bias = bias is not None
+        return out if F4 == F else out[:, :F]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        plan, F = ctx.plan, ctx.F
+        F4 = (F + 3) & ~3
+        g = _pad_cols(grad_out, F4).contiguous()
+        d_xw = d_bias = None
+        if ctx.needs_input_grad[1]:
+            d_xw = plan.spmm(g, None, transpose=True)
+            if F4 != F:
+                d_xw = d_xw[:, :F]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_bias = colsum(g)[:F]
+        return None, d_xw, d_bias
+
+
+def propagate(plan: GraphPlan, xw: Tensor, bias: Optional[Tensor]) -> Tensor:
+    if plan.n_rows != plan.num_nodes:
+        raise ValueError("propagate() needs a whole-graph plan; use pytextgcn_amd.sharded for row blocks")
+    return _Propagate.apply(plan, xw, bias)
+
+
+# sparse feature matrices that are exactly the identity (text2graph.py:179): X @ W is W itself
+_IDENTITY_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def is_sparse_identity(x: Tensor) -> bool:
+    if not x.is_sparse:
+        return False
+    hit = _IDENTITY_CACHE.get(x)
+    if hit is not None:
+        return hit
+    ok = False
+    if x.size(0) == x.size(1):
+        xc = x if x.is_coalesced() else x.coalesce()
+        idx, val = xc.indices(), xc.values()
+        if val.numel() == x.size(0):
+            ok = bool(((idx[0] == idx[1]).all() & (val == 1).all()).item())
+    _IDENTITY_CACHE[x] = ok
+    return ok
+
+
+def glorot_(t: Tensor) -> Tensor:
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        return t.uniform_(-a, a)
+
+
+class GCNConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False,
+                 cached: bool = False, add_self_loops: bool = True, normalize: bool = True,
+                 bias: bool = True, **kwargs):
+        super().__init__()
+        if improved:
+            raise NotImplementedError("improved=True (loop weight 2) is never used by PyTextGCN")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.improved = improved
+        self.cached = cached                  # accepted for signature parity; plans are always cached
+        self.add_self_loops = add_self_loops
+        self.normalize = normalize
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        glorot_(self.weight)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
+        plan = plan_for(edge_index, edge_weight, x.size(0), self.add_self_loops, self.normalize)
+        if x.is_sparse:
+            if x.size(1) != self.in_channels:
+                raise ValueError(f"x has {x.size(1)} features, the layer expects {self.in_channels}")
+            # layer 1 of TextGCN: one-hot features, so X @ W1 is W1 (and dW1 = dXW, no GEMM)
+            xw = self.weight if is_sparse_identity(x) else torch.sparse.mm(x, self.weight)
+        else:
+            xw = torch.matmul(x, self.weight)
+        return propagate(plan, xw, self.bias)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

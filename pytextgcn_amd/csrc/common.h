@@ -1,0 +1,90 @@
+// Internal declarations shared by the translation units of libtgcn.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "tgcn.h"
+
+namespace tgcn {
+
+// thread-local message behind tgcn_last_error()
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define TGCN_HIP_CHECK(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            ::tgcn::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,         \
+                              __LINE__);                                                        \
+            return e_ == hipErrorOutOfMemory ? TGCN_E_NOMEM : TGCN_E_HIP;                       \
+        }                                                                                       \
+    } while (0)
+
+#define TGCN_CHECK(call)                                                                        \
+    do {                                                                                        \
+        int s_ = (call);                                                                        \
+        if (s_ != TGCN_OK) return s_;                                                           \
+    } while (0)
+
+// One wavefront's task in the SpMM kernel.
+//   row block : rows [row_begin, row_end) complete, their non-zeros [nnz_begin, nnz_end) contiguous
+//   segment   : row_end < 0; part [nnz_begin, nnz_end) of the single long row `row_begin`, whose
+//               partial sum goes to carry row (-row_end - 1)
+struct WorkItem {
+    int32_t row_begin;
+    int32_t row_end;
+    int32_t nnz_begin;
+    int32_t nnz_end;
+};
+
+// A long row and where its partial sums sit: carry rows [slot_begin, slot_begin + count).
+struct FixEntry {
+    int32_t row;
+    int32_t slot_begin;
+    int32_t count;
+    int32_t pad;
+};
+
+// One stored operator block (rows [row_begin,row_end) of M or of M^T) in device memory.
+struct CsrBlock {
+    int64_t n_rows = 0;
+    int64_t n_cols = 0;
+    int64_t nnz = 0;
+    int32_t *rowptr = nullptr;  // [n_rows + 1]
+    int2 *cv = nullptr;         // [nnz] {col, bits(val)}
+    WorkItem *items = nullptr;  // [n_items]
+    int32_t n_items = 0;
+    FixEntry *fix = nullptr;    // [n_fix]
+    int32_t n_fix = 0;
+    int32_t n_segments = 0;
+    size_t bytes = 0;
+};
+
+void free_block(CsrBlock &b);
+
+// Host-side partition of a block into work items (plan.hip); item_weight = target nnz+rows per item.
+int build_items(CsrBlock &b, int item_weight, hipStream_t stream);
+
+// Kernel launchers (spmm.hip / colsum.hip); arguments validated by the caller.
+int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
+                int64_t ldy, float *carry, hipStream_t stream);
+int launch_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out, float *partial,
+                  int n_blocks, hipStream_t stream);
+int colsum_blocks(int64_t n_rows);
+
+inline int64_t round_up4(int64_t v) { return (v + 3) & ~int64_t(3); }
+
+}  // namespace tgcn
+
+struct tgcn_plan {
+    int device = 0;
+    int64_t n_nodes = 0;
+    int64_t row_begin = 0;
+    int64_t row_end = 0;
+    bool symmetric = false;
+    tgcn::CsrBlock fwd;
+    tgcn::CsrBlock bwd;  // unused when symmetric
+};

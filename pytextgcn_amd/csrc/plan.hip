@@ -1,0 +1,579 @@
+// Plan construction: COO edge list -> normalised operator M (and M^T) in CSR + work-item partition.
+//
+// Replaces PyG-1.6.3 gcn_norm / add_remaining_self_loops, which the reference re-executes inside
+// every GCNConv call (textgcn/lib/models.py:11-15 construct the layers with cached=False and
+// models.py:20 calls them): here it runs once per graph, on the device, and is kept.
+// One-off work, so the sort is rocPRIM's device radix sort; everything else is small hand kernels.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace tgcn {
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n) {
+        bytes = n;
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes): %s", n, hipGetErrorString(e));
+            return TGCN_E_NOMEM;
+        }
+        return TGCN_OK;
+    }
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+    void *release() {
+        void *q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
+constexpr int kThreads = 256;
+
+inline int grid_for(int64_t n, int per_block = kThreads, int cap = 1 << 20) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return static_cast<int>(g);
+}
+
+// flags[0] = index out of range seen; flags[1] = number of self-loop edges in the input
+__global__ void k_scan_edges(int64_t E, const int64_t *__restrict__ src, int64_t ss,
+                             const int64_t *__restrict__ dst, int64_t ds, int64_t N, int add_loops,
+                             unsigned long long *__restrict__ loop_eid, unsigned int *flags) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
+        const int64_t s = src[e * ss], d = dst[e * ds];
+        if (s < 0 || s >= N || d < 0 || d >= N) {
+            flags[0] = 1u;
+            continue;
+        }
+        if (add_loops && s == d) {
+            // last duplicate in edge order wins (PyG index assignment on CPU)
+            atomicMax(&loop_eid[s], static_cast<unsigned long long>(e + 1));
+            atomicAdd(&flags[1], 1u);
+        }
+    }
+}
+
+// key = dst << 32 | src; dropped entries (input self-loops when loops are re-appended) get the
+// key N << 32 so they sort behind every real row.
+__global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t ss,
+                            const int64_t *__restrict__ dst, int64_t ds,
+                            const float *__restrict__ w, int64_t N, int add_loops,
+                            const unsigned long long *__restrict__ loop_eid,
+                            uint64_t *__restrict__ keys, float *__restrict__ vals) {
+    const int64_t total = E + (add_loops ? N : 0);
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const uint64_t drop = static_cast<uint64_t>(N) << 32;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        if (i < E) {
+            const int64_t s = src[i * ss], d = dst[i * ds];
+            const bool bad = s < 0 || s >= N || d < 0 || d >= N;
+            keys[i] = (bad || (add_loops && s == d))
+                          ? drop
+                          : (static_cast<uint64_t>(d) << 32) | static_cast<uint64_t>(s);
+            vals[i] = w ? w[i] : 1.0f;
+        } else {
+            const int64_t n = i - E;
+            const unsigned long long le = loop_eid[n];
+            keys[i] = (static_cast<uint64_t>(n) << 32) | static_cast<uint64_t>(n);
+            vals[i] = le ? (w ? w[le - 1] : 1.0f) : 1.0f;
+        }
+    }
+}
+
+// rowptr[r] = first position whose key has row >= r
+__global__ void k_rowptr(const uint64_t *__restrict__ keys, int64_t nnz, int64_t N,
+                         int32_t *__restrict__ rowptr) {
+    const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r > N) return;
+    const uint64_t target = static_cast<uint64_t>(r) << 32;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rowptr[r] = static_cast<int32_t>(lo);
+}
+
+// One wavefront per row: weighted in-degree (loop included), then deg^-1/2 with inf -> 0.
+__global__ void k_deg_inv_sqrt(const int32_t *__restrict__ rowptr, const float *__restrict__ vals,
+                               int64_t N, float *__restrict__ dis) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    float s = 0.0f;
+    for (int32_t j = b + lane; j < e; j += 64) s += vals[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+        float d = 1.0f / sqrtf(s);  // deg.pow(-0.5)
+        if (isinf(d)) d = 0.0f;     // masked_fill_(== inf, 0)
+        dis[r] = d;
+    }
+}
+
+// w_hat = dis[src] * w * dis[dst] (PyG's left-to-right order); emits the CSR pair array of M and
+// the (src << 32 | dst, w_hat) pairs that are sorted next to give M^T.
+__global__ void k_finalize(const uint64_t *__restrict__ keys, const float *__restrict__ vals,
+                           int64_t nnz, const float *__restrict__ dis, int normalize,
+                           int2 *__restrict__ cv, uint64_t *__restrict__ keys_t,
+                           float *__restrict__ vals_t) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const uint64_t k = keys[j];
+        const uint32_t d = static_cast<uint32_t>(k >> 32), s = static_cast<uint32_t>(k);
+        float v = vals[j];
+        if (normalize) v = dis[s] * v * dis[d];
+        cv[j] = make_int2(static_cast<int>(s), __float_as_int(v));
+        keys_t[j] = (static_cast<uint64_t>(s) << 32) | d;
+        vals_t[j] = v;
+    }
+}
+
+__global__ void k_unpack(const uint64_t *__restrict__ keys, const float *__restrict__ vals,
+                         int64_t nnz, int2 *__restrict__ cv) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride)
+        cv[j] = make_int2(static_cast<int>(static_cast<uint32_t>(keys[j])), __float_as_int(vals[j]));
+}
+
+__global__ void k_compare(const int32_t *__restrict__ rp_a, const int32_t *__restrict__ rp_b,
+                          int64_t n_rp, const int2 *__restrict__ cv_a,
+                          const int2 *__restrict__ cv_b, int64_t nnz, unsigned int *differ) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    bool diff = false;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_rp; i += stride)
+        diff |= rp_a[i] != rp_b[i];
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const int2 a = cv_a[j], b = cv_b[j];
+        diff |= (a.x != b.x) | (a.y != b.y);
+    }
+    if (diff) *differ = 1u;
+}
+
+__global__ void k_slice_rowptr(const int32_t *__restrict__ rowptr, int64_t row_begin,
+                               int64_t n_rows, int32_t *__restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i <= n_rows) out[i] = rowptr[row_begin + i] - rowptr[row_begin];
+}
+
+int sort_pairs(uint64_t *keys_in, uint64_t *keys_out, float *vals_in, float *vals_out, int64_t n,
+               unsigned end_bit, hipStream_t stream) {
+    if (n == 0) return TGCN_OK;
+    size_t tmp_bytes = 0;
+    TGCN_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in,
+                                             vals_out, static_cast<size_t>(n), 0u, end_bit, stream));
+    DevBuf tmp;
+    TGCN_CHECK(tmp.alloc(tmp_bytes));
+    TGCN_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                             static_cast<size_t>(n), 0u, end_bit, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));  // tmp is freed on return
+    return TGCN_OK;
+}
+
+// Keep rows [row_begin, row_end) of a full CSR as an owned block.
+int take_block(const int32_t *rowptr_full, const int2 *cv_full, int64_t n_nodes, int64_t row_begin,
+               int64_t row_end, CsrBlock &out, hipStream_t stream) {
+    int32_t ends[2];
+    TGCN_HIP_CHECK(hipMemcpyAsync(&ends[0], rowptr_full + row_begin, sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipMemcpyAsync(&ends[1], rowptr_full + row_end, sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    out.n_rows = row_end - row_begin;
+    out.n_cols = n_nodes;
+    out.nnz = int64_t(ends[1]) - ends[0];
+    DevBuf rp, cv;
+    TGCN_CHECK(rp.alloc(sizeof(int32_t) * (out.n_rows + 1)));
+    TGCN_CHECK(cv.alloc(sizeof(int2) * out.nnz));
+    k_slice_rowptr<<<grid_for(out.n_rows + 1), kThreads, 0, stream>>>(rowptr_full, row_begin,
+                                                                     out.n_rows, rp.as<int32_t>());
+    TGCN_HIP_CHECK(hipGetLastError());
+    if (out.nnz)
+        TGCN_HIP_CHECK(hipMemcpyAsync(cv.p, cv_full + ends[0], sizeof(int2) * out.nnz,
+                                      hipMemcpyDeviceToDevice, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    out.bytes = rp.bytes + cv.bytes;
+    out.rowptr = static_cast<int32_t *>(rp.release());
+    out.cv = static_cast<int2 *>(cv.release());
+    return TGCN_OK;
+}
+
+int item_weight_from_env() {
+    const char *s = std::getenv("TGCN_ITEM_WEIGHT");
+    int v = s ? std::atoi(s) : 0;
+    if (v < 64 || v > (1 << 20)) v = 512;
+    return v;
+}
+
+}  // namespace
+
+void free_block(CsrBlock &b) {
+    if (b.rowptr) (void)hipFree(b.rowptr);
+    if (b.cv) (void)hipFree(b.cv);
+    if (b.items) (void)hipFree(b.items);
+    if (b.fix) (void)hipFree(b.fix);
+    b = CsrBlock{};
+}
+
+// Greedy host-side partition (one pass over rowptr, a few ms at 2 M rows):
+//   rows of degree <= T are packed, whole, into blocks of weight ~T (weight of a row = degree + 1:
+//   its gathered rows plus its output row); a row of degree > T is cut into ceil(deg/T) equal
+//   segments whose partial sums a second pass adds up in a fixed order.
+int build_items(CsrBlock &b, int T, hipStream_t stream) {
+    std::vector<int32_t> rp(static_cast<size_t>(b.n_rows) + 1);
+    TGCN_HIP_CHECK(hipMemcpyAsync(rp.data(), b.rowptr, sizeof(int32_t) * rp.size(),
+                                  hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<WorkItem> items;
+    std::vector<FixEntry> fix;
+    items.reserve(static_cast<size_t>((b.nnz + b.n_rows) / T + 16));
+    int64_t slots = 0;
+    int32_t r0 = 0;
+    int64_t wsum = 0;
+    const int32_t n_rows = static_cast<int32_t>(b.n_rows);
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const int32_t d = rp[r + 1] - rp[r];
+        if (d > T) {
+            if (r > r0) items.push_back({r0, r, rp[r0], rp[r]});
+            const int32_t nseg = (d + T - 1) / T;
+            const int32_t seglen = (d + nseg - 1) / nseg;
+            fix.push_back({r, static_cast<int32_t>(slots), nseg, 0});
+            for (int32_t s = 0; s < nseg; ++s) {
+                const int32_t nb = std::min(rp[r] + s * seglen, rp[r + 1]);
+                const int32_t ne = std::min(nb + seglen, rp[r + 1]);
+                items.push_back({r, -static_cast<int32_t>(slots + s) - 1, nb, ne});
+            }
+            slots += nseg;
+            r0 = r + 1;
+            wsum = 0;
+        } else {
+            wsum += d + 1;
+            if (wsum >= T) {
+                items.push_back({r0, r + 1, rp[r0], rp[r + 1]});
+                r0 = r + 1;
+                wsum = 0;
+            }
+        }
+    }
+    if (r0 < n_rows) items.push_back({r0, n_rows, rp[r0], rp[n_rows]});
+    if (slots > INT32_MAX || items.size() > size_t(INT32_MAX)) {
+        set_error("work partition exceeds int32 limits");
+        return TGCN_E_RANGE;
+    }
+    b.n_items = static_cast<int32_t>(items.size());
+    b.n_fix = static_cast<int32_t>(fix.size());
+    b.n_segments = static_cast<int32_t>(slots);
+    DevBuf d_items, d_fix;
+    TGCN_CHECK(d_items.alloc(sizeof(WorkItem) * items.size()));
+    TGCN_CHECK(d_fix.alloc(sizeof(FixEntry) * fix.size()));
+    if (!items.empty())
+        TGCN_HIP_CHECK(hipMemcpyAsync(d_items.p, items.data(), sizeof(WorkItem) * items.size(),
+                                      hipMemcpyHostToDevice, stream));
+    if (!fix.empty())
+        TGCN_HIP_CHECK(hipMemcpyAsync(d_fix.p, fix.data(), sizeof(FixEntry) * fix.size(),
+                                      hipMemcpyHostToDevice, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors die on return
+    b.bytes += d_items.bytes + d_fix.bytes;
+    b.items = static_cast<WorkItem *>(d_items.release());
+    b.fix = static_cast<FixEntry *>(d_fix.release());
+    return TGCN_OK;
+}
+
+namespace {
+
+int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const int64_t *dst,
+                     int64_t ds, const float *w, int add_loops, int normalize, int64_t row_begin,
+                     int64_t row_end, hipStream_t stream, tgcn_plan &plan) {
+    const int64_t total = E + (add_loops ? N : 0);
+    if (N >= (int64_t(1) << 31) - 1 || total >= (int64_t(1) << 31) - 1) {
+        set_error("n_nodes=%lld / n_edges=%lld exceed the int32 index range of this build",
+                  (long long)N, (long long)E);
+        return TGCN_E_RANGE;
+    }
+
+    DevBuf loop_eid, flags, keys_a, keys_b, vals_a, vals_b, rowptr, rowptr_t, dis, cv, cv_t;
+    TGCN_CHECK(loop_eid.alloc(sizeof(unsigned long long) * (add_loops ? N : 1)));
+    TGCN_CHECK(flags.alloc(sizeof(unsigned int) * 4));
+    TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
+    TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
+    TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
+    TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
+    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(rowptr_t.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(dis.alloc(sizeof(float) * N));
+    TGCN_HIP_CHECK(hipMemsetAsync(loop_eid.p, 0, loop_eid.bytes ? loop_eid.bytes : 16, stream));
+    TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
+
+    if (E > 0) {
+        k_scan_edges<<<grid_for(E, kThreads, 4096), kThreads, 0, stream>>>(
+            E, src, ss, dst, ds, N, add_loops, loop_eid.as<unsigned long long>(),
+            flags.as<unsigned int>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    unsigned int h_flags[4] = {0, 0, 0, 0};
+    TGCN_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_flags[0]) {
+        set_error("edge_index holds a node id outside [0, %lld)", (long long)N);
+        return TGCN_E_RANGE;
+    }
+    const int64_t nnz = total - (add_loops ? int64_t(h_flags[1]) : 0);
+
+    if (total > 0) {
+        k_make_keys<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
+            E, src, ss, dst, ds, w, N, add_loops, loop_eid.as<unsigned long long>(),
+            keys_a.as<uint64_t>(), vals_a.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    unsigned node_bits = 1;
+    while ((int64_t(1) << node_bits) <= N) ++node_bits;  // the drop key N << 32 must sort too
+    const unsigned end_bit = 32 + node_bits;
+    // stable: duplicate (dst, src) pairs keep their edge order, so sums are deterministic
+    TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
+                          vals_b.as<float>(), total, end_bit, stream));
+
+    k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), nnz, N,
+                                                       rowptr.as<int32_t>());
+    TGCN_HIP_CHECK(hipGetLastError());
+    if (normalize && N > 0) {
+        k_deg_inv_sqrt<<<grid_for(N, kThreads / 64), kThreads, 0, stream>>>(
+            rowptr.as<int32_t>(), vals_b.as<float>(), N, dis.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    TGCN_CHECK(cv.alloc(sizeof(int2) * nnz));
+    TGCN_CHECK(cv_t.alloc(sizeof(int2) * nnz));
+    if (nnz > 0) {
+        k_finalize<<<grid_for(nnz, kThreads, 8192), kThreads, 0, stream>>>(
+            keys_b.as<uint64_t>(), vals_b.as<float>(), nnz, dis.as<float>(), normalize,
+            cv.as<int2>(), keys_a.as<uint64_t>(), vals_a.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    // transposed operator: sort by (src, dst)
+    TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
+                          vals_b.as<float>(), nnz, end_bit, stream));
+    k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), nnz, N,
+                                                       rowptr_t.as<int32_t>());
+    TGCN_HIP_CHECK(hipGetLastError());
+    if (nnz > 0) {
+        k_unpack<<<grid_for(nnz, kThreads, 8192), kThreads, 0, stream>>>(
+            keys_b.as<uint64_t>(), vals_b.as<float>(), nnz, cv_t.as<int2>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
+    k_compare<<<grid_for(std::max<int64_t>(nnz, N + 1), kThreads, 4096), kThreads, 0, stream>>>(
+        rowptr.as<int32_t>(), rowptr_t.as<int32_t>(), N + 1, cv.as<int2>(), cv_t.as<int2>(), nnz,
+        flags.as<unsigned int>());
+    TGCN_HIP_CHECK(hipGetLastError());
+    TGCN_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    plan.symmetric = h_flags[0] == 0;
+
+    // sort scratch is no longer needed: release it before the blocks are copied out
+    (void)hipFree(keys_a.release());
+    (void)hipFree(keys_b.release());
+    (void)hipFree(vals_a.release());
+    (void)hipFree(vals_b.release());
+
+    const int T = item_weight_from_env();
+    const bool whole = row_begin == 0 && row_end == N;
+    if (whole) {
+        plan.fwd.n_rows = N;
+        plan.fwd.n_cols = N;
+        plan.fwd.nnz = nnz;
+        plan.fwd.bytes = rowptr.bytes + cv.bytes;
+        plan.fwd.rowptr = static_cast<int32_t *>(rowptr.release());
+        plan.fwd.cv = static_cast<int2 *>(cv.release());
+    } else {
+        TGCN_CHECK(take_block(rowptr.as<int32_t>(), cv.as<int2>(), N, row_begin, row_end, plan.fwd,
+                              stream));
+    }
+    TGCN_CHECK(build_items(plan.fwd, T, stream));
+    if (!plan.symmetric) {
+        if (whole) {
+            plan.bwd.n_rows = N;
+            plan.bwd.n_cols = N;
+            plan.bwd.nnz = nnz;
+            plan.bwd.bytes = rowptr_t.bytes + cv_t.bytes;
+            plan.bwd.rowptr = static_cast<int32_t *>(rowptr_t.release());
+            plan.bwd.cv = static_cast<int2 *>(cv_t.release());
+        } else {
+            TGCN_CHECK(take_block(rowptr_t.as<int32_t>(), cv_t.as<int2>(), N, row_begin, row_end,
+                                  plan.bwd, stream));
+        }
+        TGCN_CHECK(build_items(plan.bwd, T, stream));
+    }
+    return TGCN_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        TGCN_HIP_CHECK(hipGetDevice(&prev));
+        if (prev != device) {
+            TGCN_HIP_CHECK(hipSetDevice(device));
+            switched = true;
+        }
+        return TGCN_OK;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+}  // namespace tgcn
+
+extern "C" {
+
+int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t src_stride,
+                     const int64_t *dst, int64_t dst_stride, const float *w, int add_self_loops,
+                     int normalize, int64_t row_begin, int64_t row_end, int device,
+                     tgcn_stream stream, tgcn_plan **out) {
+    using namespace tgcn;
+    if (!out) {
+        set_error("tgcn_plan_create: out is NULL");
+        return TGCN_E_INVALID;
+    }
+    *out = nullptr;
+    if (n_nodes <= 0 || n_edges < 0) {
+        set_error("tgcn_plan_create: n_nodes=%lld must be > 0 and n_edges=%lld >= 0",
+                  (long long)n_nodes, (long long)n_edges);
+        return TGCN_E_INVALID;
+    }
+    if (n_edges > 0 && (!src || !dst || src_stride <= 0 || dst_stride <= 0)) {
+        set_error("tgcn_plan_create: src/dst must be non-NULL with positive strides");
+        return TGCN_E_INVALID;
+    }
+    if (row_begin < 0 || row_end < row_begin || row_end > n_nodes) {
+        set_error("tgcn_plan_create: row range [%lld, %lld) outside [0, %lld]", (long long)row_begin,
+                  (long long)row_end, (long long)n_nodes);
+        return TGCN_E_INVALID;
+    }
+    DeviceGuard guard;
+    TGCN_CHECK(guard.enter(device));
+    tgcn_plan *plan = new (std::nothrow) tgcn_plan();
+    if (!plan) {
+        set_error("tgcn_plan_create: host allocation failed");
+        return TGCN_E_NOMEM;
+    }
+    plan->device = device;
+    plan->n_nodes = n_nodes;
+    plan->row_begin = row_begin;
+    plan->row_end = row_end;
+    const int st = plan_create_impl(n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
+                                    add_self_loops != 0, normalize != 0, row_begin, row_end,
+                                    static_cast<hipStream_t>(stream), *plan);
+    if (st != TGCN_OK) {
+        free_block(plan->fwd);
+        free_block(plan->bwd);
+        delete plan;
+        return st;
+    }
+    *out = plan;
+    return TGCN_OK;
+}
+
+int tgcn_plan_destroy(tgcn_plan *plan) {
+    using namespace tgcn;
+    if (!plan) return TGCN_OK;
+    DeviceGuard guard;
+    TGCN_CHECK(guard.enter(plan->device));
+    free_block(plan->fwd);
+    free_block(plan->bwd);
+    delete plan;
+    return TGCN_OK;
+}
+
+int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out) {
+    using namespace tgcn;
+    if (!plan || !out) {
+        set_error("tgcn_plan_query: NULL argument");
+        return TGCN_E_INVALID;
+    }
+    const CsrBlock &f = plan->fwd;
+    const CsrBlock &t = plan->symmetric ? plan->fwd : plan->bwd;
+    switch (what) {
+        case TGCN_Q_N_NODES: *out = plan->n_nodes; break;
+        case TGCN_Q_N_ROWS: *out = plan->row_end - plan->row_begin; break;
+        case TGCN_Q_NNZ: *out = f.nnz; break;
+        case TGCN_Q_NNZ_T: *out = t.nnz; break;
+        case TGCN_Q_SYMMETRIC: *out = plan->symmetric ? 1 : 0; break;
+        case TGCN_Q_ITEMS: *out = f.n_items; break;
+        case TGCN_Q_ITEMS_T: *out = t.n_items; break;
+        case TGCN_Q_LONG_ROWS: *out = f.n_fix; break;
+        case TGCN_Q_LONG_ROWS_T: *out = t.n_fix; break;
+        case TGCN_Q_SEGMENTS: *out = f.n_segments; break;
+        case TGCN_Q_SEGMENTS_T: *out = t.n_segments; break;
+        case TGCN_Q_DEVICE_BYTES:
+            *out = static_cast<int64_t>(f.bytes + (plan->symmetric ? 0 : plan->bwd.bytes));
+            break;
+        case TGCN_Q_ROW_BEGIN: *out = plan->row_begin; break;
+        default:
+            set_error("tgcn_plan_query: unknown selector %d", what);
+            return TGCN_E_INVALID;
+    }
+    return TGCN_OK;
+}
+
+namespace {
+__global__ void k_export(const int2 *__restrict__ cv, int64_t nnz, int32_t *col, float *val) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const int2 p = cv[j];
+        if (col) col[j] = p.x;
+        if (val) val[j] = __int_as_float(p.y);
+    }
+}
+}  // namespace
+
+int tgcn_plan_export(const tgcn_plan *plan, int transpose, int32_t *rowptr, int32_t *col, float *val,
+                     tgcn_stream stream) {
+    using namespace tgcn;
+    if (!plan) {
+        set_error("tgcn_plan_export: plan is NULL");
+        return TGCN_E_INVALID;
+    }
+    DeviceGuard guard;
+    TGCN_CHECK(guard.enter(plan->device));
+    const CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rowptr)
+        TGCN_HIP_CHECK(hipMemcpyAsync(rowptr, b.rowptr, sizeof(int32_t) * (b.n_rows + 1),
+                                      hipMemcpyDeviceToDevice, s));
+    if ((col || val) && b.nnz > 0) {
+        k_export<<<grid_for(b.nnz, kThreads, 8192), kThreads, 0, s>>>(b.cv, b.nnz, col, val);
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    return TGCN_OK;
+}
+
+}  // extern "C"

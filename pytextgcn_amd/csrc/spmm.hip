@@ -1,0 +1,259 @@
+// CSR SpMM  Y = M X (+ bias)  for gfx950: the message-passing step of GCNConv.
+//
+// Replaces, fused into one pass, what PyG-1.6.3 does at textgcn/lib/models.py:20 as index_select
+// (nnz x F gather), broadcast multiply (another nnz x F) and scatter_add (k6-k8 of SURVEY.md 2a)
+// plus `out += bias` (k9); called with the transposed block it is that step's autograd.
+//
+// Shape of the kernel (HBM-bound: ~0.5 flop/byte at F = 200):
+//   * one wavefront (64 lanes) per work item; an item is ~T non-zeros: either a block of complete
+//     short rows or one segment of a long row (common.h).  All waves carry equal work, so degree
+//     skew costs nothing and no output row is ever shared between waves (no atomics).
+//   * the wave streams its (col,val) pairs 64 at a time with one coalesced 8-byte load per lane and
+//     hands them out through v_readlane: column id and weight live in SGPRs, so a gathered row is
+//     one `global_load_dwordx4 v, v_off, s[base]` per lane -- lane l owns columns 4l..4l+3, 50 of
+//     64 lanes busy at F = 200, the rest are clamped onto the last vector (same cache line, no
+//     extra traffic) so the wave never diverges.
+//   * U gathered rows are in flight per wave before the first FMA (U x 800 B at F = 200); with
+//     >= 4 waves per SIMD that is > 100 KB of loads in flight per CU, enough to cover HBM latency.
+//   * row sums stay in registers; a finished row is written once, with the bias added.  Long rows
+//     write one partial per segment into the carry workspace and k_spmm_fix adds them in slot
+//     order (LDS across the 4 waves), so the result is bitwise reproducible.
+#include "common.h"
+
+namespace tgcn {
+namespace {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    using type = float4;
+    static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void fma(type &a, float v, const type &x) {
+        a.x = fmaf(v, x.x, a.x);
+        a.y = fmaf(v, x.y, a.y);
+        a.z = fmaf(v, x.z, a.z);
+        a.w = fmaf(v, x.w, a.w);
+    }
+    static __device__ __forceinline__ type add(const type &a, const type &b) {
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+};
+template <>
+struct Vec<1> {
+    using type = float;
+    static __device__ __forceinline__ type zero() { return 0.f; }
+    static __device__ __forceinline__ void fma(type &a, float v, const type &x) { a = fmaf(v, x, a); }
+    static __device__ __forceinline__ type add(const type &a, const type &b) { return a + b; }
+};
+
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float readlane_f(int bits, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(bits, lane));
+}
+
+constexpr int kWavesPerBlock = 4;
+
+// grid.x = ceil(n_items / 4), grid.y = column tiles of 64*VEC floats
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_spmm_gather(
+    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
+    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
+    int64_t ldc) {
+    using V = Vec<VEC>;
+    using vec_t = typename V::type;
+    const int lane = threadIdx.x & 63;
+    const int item_id =
+        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item_id >= n_items) return;
+
+    const int col0 = blockIdx.y * (64 * VEC);
+    const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;  // vectors in this column tile
+    const bool active = lane < nvec;
+    const int lc = col0 + (active ? lane : nvec - 1) * VEC;      // idle lanes shadow the last one
+
+    const WorkItem it = items[item_id];
+    const int nnz_end = it.nnz_end;
+    const bool segment = it.row_end < 0;
+
+    vec_t bvec = V::zero();
+    if (bias != nullptr) bvec = *reinterpret_cast<const vec_t *>(bias + lc);
+
+    // end offsets of the next 64 rows, one per lane (row blocks only)
+    int r = it.row_begin;
+    int rp_base = r;
+    int rp_lane = nnz_end;
+    if (!segment && r + lane < it.row_end) rp_lane = rowptr[r + 1 + lane];
+    int row_end = segment ? nnz_end : readlane_i(rp_lane, 0);
+
+    vec_t acc = V::zero();
+    const float *xl = X + lc;
+
+    auto flush_row = [&]() {
+        // row r is complete: write it, move to the next one
+        if (active) *reinterpret_cast<vec_t *>(Y + int64_t(r) * ldy + lc) = V::add(acc, bvec);
+        acc = V::zero();
+        ++r;
+        if (r - rp_base == 64) {
+            rp_base = r;
+            rp_lane = nnz_end;
+            if (r + lane < it.row_end) rp_lane = rowptr[r + 1 + lane];
+        }
+        row_end = readlane_i(rp_lane, r - rp_base);
+    };
+
+    int2 cur = make_int2(0, 0);
+    if (it.nnz_begin + lane < nnz_end) cur = cv[it.nnz_begin + lane];
+    for (int base = it.nnz_begin; base < nnz_end; base += 64) {
+        const int2 mine = cur;
+        cur = make_int2(0, 0);  // col 0 / weight 0: a harmless row for the padded tail
+        if (base + 64 + lane < nnz_end) cur = cv[base + 64 + lane];
+        const int n = min(64, nnz_end - base);
+        for (int j0 = 0; j0 < n; j0 += U) {
+            vec_t x[U];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = readlane_i(mine.x, j0 + u);
+                v[u] = readlane_f(mine.y, j0 + u);
+                x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + j0 + u;
+                if (idx < nnz_end) {
+                    if (!segment) {
+                        while (idx == row_end) flush_row();
+                    }
+                    V::fma(acc, v[u], x[u]);
+                }
+            }
+        }
+    }
+    if (segment) {
+        const int slot = -it.row_end - 1;
+        if (active) *reinterpret_cast<vec_t *>(carry + int64_t(slot) * ldc + lc) = acc;
+    } else {
+        // last row with entries, then any trailing empty rows of the block
+        while (r < it.row_end) {
+            if (active) *reinterpret_cast<vec_t *>(Y + int64_t(r) * ldy + lc) = V::add(acc, bvec);
+            acc = V::zero();
+            ++r;
+        }
+    }
+}
+
+// One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
+// Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ fix,
+                                                  const float *__restrict__ carry, int64_t ldc,
+                                                  const float *__restrict__ bias,
+                                                  float *__restrict__ Y, int64_t ldy, int F) {
+    using V = Vec<VEC>;
+    using vec_t = typename V::type;
+    __shared__ vec_t red[kWavesPerBlock][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col0 = blockIdx.y * (64 * VEC);
+    const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;
+    const bool active = lane < nvec;
+    const int lc = col0 + (active ? lane : nvec - 1) * VEC;
+    const FixEntry fe = fix[blockIdx.x];
+    const float *base = carry + int64_t(fe.slot_begin) * ldc + lc;
+    vec_t acc = V::zero();
+    int s = wave;
+    for (; s + 3 * kWavesPerBlock < fe.count; s += 4 * kWavesPerBlock) {
+        const vec_t a0 = *reinterpret_cast<const vec_t *>(base + int64_t(s) * ldc);
+        const vec_t a1 = *reinterpret_cast<const vec_t *>(base + int64_t(s + kWavesPerBlock) * ldc);
+        const vec_t a2 = *reinterpret_cast<const vec_t *>(base + int64_t(s + 2 * kWavesPerBlock) * ldc);
+        const vec_t a3 = *reinterpret_cast<const vec_t *>(base + int64_t(s + 3 * kWavesPerBlock) * ldc);
+        acc = V::add(V::add(V::add(V::add(acc, a0), a1), a2), a3);
+    }
+    for (; s < fe.count; s += kWavesPerBlock)
+        acc = V::add(acc, *reinterpret_cast<const vec_t *>(base + int64_t(s) * ldc));
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && active) {
+        vec_t t = V::add(V::add(red[0][lane], red[1][lane]), V::add(red[2][lane], red[3][lane]));
+        if (bias != nullptr) t = V::add(t, *reinterpret_cast<const vec_t *>(bias + lc));
+        *reinterpret_cast<vec_t *>(Y + int64_t(fe.row) * ldy + lc) = t;
+    }
+}
+
+template <int VEC>
+int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
+               int64_t ldy, float *carry, hipStream_t stream) {
+    constexpr int U = 8;
+    const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
+    const int64_t ldc = round_up4(F);
+    if (b.n_items > 0) {
+        dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+        k_spmm_gather<VEC, U><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx,
+                                                        F, bias, Y, ldy, carry, ldc);
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    if (b.n_fix > 0) {
+        dim3 grid(b.n_fix, tiles);
+        k_spmm_fix<VEC><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, Y, ldy, F);
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    return TGCN_OK;
+}
+
+}  // namespace
+
+int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
+                int64_t ldy, float *carry, hipStream_t stream) {
+    const uintptr_t align = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
+                            reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(carry);
+    const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (align % 16 == 0);
+    return vec4 ? launch_vec<4>(b, X, ldx, F, bias, Y, ldy, carry, stream)
+                : launch_vec<1>(b, X, ldx, F, bias, Y, ldy, carry, stream);
+}
+
+}  // namespace tgcn
+
+extern "C" {
+
+size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F) {
+    if (!plan || F <= 0) return 0;
+    const tgcn::CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
+    return sizeof(float) * static_cast<size_t>(b.n_segments) * static_cast<size_t>(tgcn::round_up4(F));
+}
+
+int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, int F,
+              const float *bias, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
+              tgcn_stream stream) {
+    using namespace tgcn;
+    if (!plan || !X || !Y) {
+        set_error("tgcn_spmm: NULL plan/X/Y");
+        return TGCN_E_INVALID;
+    }
+    if (F <= 0 || ldx < F || ldy < F) {
+        set_error("tgcn_spmm: need F > 0 and ldx, ldy >= F (F=%d ldx=%lld ldy=%lld)", F,
+                  (long long)ldx, (long long)ldy);
+        return TGCN_E_INVALID;
+    }
+    const size_t need = tgcn_spmm_workspace_bytes(plan, transpose, F);
+    if (need > 0 && (!workspace || workspace_bytes < need)) {
+        set_error("tgcn_spmm: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        return TGCN_E_WORKSPACE;
+    }
+    if (need > 0 && reinterpret_cast<uintptr_t>(workspace) % 16 != 0) {
+        set_error("tgcn_spmm: workspace must be 16-byte aligned");
+        return TGCN_E_INVALID;
+    }
+    const CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
+    if (b.n_rows == 0) return TGCN_OK;
+    int cur = -1;
+    TGCN_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != plan->device) TGCN_HIP_CHECK(hipSetDevice(plan->device));
+    const int st = launch_spmm(b, X, ldx, F, bias, Y, ldy, need ? static_cast<float *>(workspace) : nullptr,
+                               static_cast<hipStream_t>(stream));
+    if (cur != plan->device) (void)hipSetDevice(cur);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+"""GraphPlan: the cached, device-resident normalised operator behind GCNConv.
+
+Host-side owner of an opaque `tgcn_plan` (include/tgcn.h).  It replaces what PyG-1.6.3
+`gcn_norm` recomputes on every layer call in the reference (textgcn/lib/models.py:11-15 build the
+layers with cached=False; models.py:20 calls them 4x per epoch) by one device-side build per graph.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"pytextgcn_amd: `{name}` lives on {t.device}; the GCN path runs only on an AMD GPU "
+            "through libtgcn.so (there is no CPU fallback)")
+
+
+class GraphPlan:
+    """M = D^-1/2 (A + I') D^-1/2 with M[target, source], rows [row_begin, row_end), kept in HBM
+    as CSR with interleaved (col, val) pairs, plus M^T unless the operator is symmetric."""
+
+    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+                 add_self_loops: bool = True, normalize: bool = True,
+                 row_range: Optional[Tuple[int, int]] = None):
+        lib = _lib.load()
+        _require_cuda(edge_index, "edge_index")
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+        if edge_index.dtype != torch.int64:
+            edge_index = edge_index.long()
+        self.device = edge_index.device
+        n_edges = edge_index.size(1)
+        if edge_weight is not None:
+            _require_cuda(edge_weight, "edge_weight")
+            if edge_weight.numel() != n_edges:
+                raise ValueError(f"edge_weight has {edge_weight.numel()} entries for {n_edges} edges")
+            edge_weight = edge_weight.detach().reshape(-1).float().contiguous()
+        src, dst = edge_index[0], edge_index[1]           # views; strides are passed through
+        row_begin, row_end = (0, num_nodes) if row_range is None else row_range
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.tgcn_plan_create(
+                num_nodes, n_edges,
+                src.data_ptr() if n_edges else None, src.stride(0) if n_edges else 1,
+                dst.data_ptr() if n_edges else None, dst.stride(0) if n_edges else 1,
+                edge_weight.data_ptr() if edge_weight is not None else None,
+                int(add_self_loops), int(normalize), row_begin, row_end,
+                self.device.index if self.device.index is not None else torch.cuda.current_device(),
+                _stream_ptr(self.device), ctypes.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.num_nodes = int(num_nodes)
+        self.row_begin, self.row_end = int(row_begin), int(row_end)
+        self.n_rows = self.row_end - self.row_begin
+        self.nnz = self.query(_lib.Q_NNZ)
+        self.nnz_t = self.query(_lib.Q_NNZ_T)
+        self.symmetric = bool(self.query(_lib.Q_SYMMETRIC))
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            self._lib.tgcn_plan_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- introspection ----------------------------------------------------------------------
+    def query(self, what: int) -> int:
+        out = ctypes.c_int64()
+        _lib.check(self._lib.tgcn_plan_query(self._h, what, ctypes.byref(out)))
+        return int(out.value)
+
+    def stats(self) -> dict:
+        return {"n_nodes": self.num_nodes, "n_rows": self.n_rows, "nnz": self.nnz,
+                "symmetric": self.symmetric, "items": self.query(_lib.Q_ITEMS),
+                "long_rows": self.query(_lib.Q_LONG_ROWS), "segments": self.query(_lib.Q_SEGMENTS),
+                "device_bytes": self.query(_lib.Q_DEVICE_BYTES)}
+
+    def algorithmic_bytes(self, F: int, bias: bool = False, transpose: bool = False) -> int:
+        """SURVEY.md 8(d) / BASELINE.md gather model, unpadded F, no cache reuse assumed:
+        nnz*(4 + 4 + 4F) + n_rows*(4 + 4F) (+4F for the bias)."""
+        nnz = self.nnz_t if transpose else self.nnz
+        return nnz * (8 + 4 * F) + self.n_rows * (4 + 4 * F) + (4 * F if bias else 0)
+
+    def export_csr(self, transpose: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+        nnz = self.nnz_t if transpose else self.nnz
+        rowptr = torch.empty(self.n_rows + 1, dtype=torch.int32, device=self.device)
+        col = torch.empty(nnz, dtype=torch.int32, device=self.device)
+        val = torch.empty(nnz, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.tgcn_plan_export(self._h, int(transpose), rowptr.data_ptr(),
+                                              col.data_ptr(), val.data_ptr(),
+                                              _stream_ptr(self.device)))
+        return rowptr, col, val
+
+    # -- compute ----------------------------------------------------------------------------
+    def spmm(self, x: Tensor, bias: Optional[Tensor] = None, transpose: bool = False,
+             out: Optional[Tensor] = None) -> Tensor:
+        """out[r] = sum_j M(^T)[row_begin + r, j] x[j] (+ bias); x is [num_nodes, F] fp32."""
+        _require_cuda(x, "x")
+        if x.dtype != torch.float32 or x.dim() != 2:
+            raise TypeError(f"spmm operand must be a 2-D float32 tensor, got {x.dtype} {tuple(x.shape)}")
+        if x.size(0) != self.num_nodes:
+            raise ValueError(f"operand has {x.size(0)} rows, the graph has {self.num_nodes} nodes")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        F = x.size(1)
+        if bias is not None:
+            bias = bias.detach().float().contiguous()
+            if bias.numel() != F:
+                raise ValueError(f"bias has {bias.numel()} entries for F={F}")
+        if out is None:
+            out = torch.empty(self.n_rows, F, dtype=torch.float32, device=x.device)
+        elif out.shape != (self.n_rows, F) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError("`out` must be float32 [n_rows, F] with unit column stride")
+        ws_bytes = self._lib.tgcn_spmm_workspace_bytes(self._h, int(transpose), F)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        _lib.check(self._lib.tgcn_spmm(
+            self._h, int(transpose), x.data_ptr(), x.stride(0), F,
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
+            ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(x.device)))
+        return out
+
+
+def colsum(g: Tensor) -> Tensor:
+    """Column sums of a float32 [n, F] device matrix (the bias gradient), deterministic."""
+    lib = _lib.load()
+    _require_cuda(g, "g")
+    if g.dtype != torch.float32 or g.dim() != 2:
+        raise TypeError("colsum operand must be a 2-D float32 tensor")
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    n, F = g.shape
+    out = torch.empty(F, dtype=torch.float32, device=g.device)
+    ws_bytes = lib.tgcn_colsum_workspace_bytes(n, F)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    _lib.check(lib.tgcn_colsum(g.data_ptr(), g.stride(0), n, F, out.data_ptr(), ws.data_ptr(),
+                               ws.numel(), _stream_ptr(g.device)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# Plan cache: the graph is static across layers and epochs, so both
+# GCNConv layers and every epoch share one plan.  Entries keep the tensors alive (so a data_ptr
+# cannot be recycled under a live key) and are invalidated by in-place edits via `_version`.
+# ------------------------------------------------------------------------------------------
+_PLAN_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+_PLAN_CACHE_MAX = 4
+
+
+def _key(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, loops: bool, norm: bool):
+    k = (edge_index.device, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+         tuple(edge_index.stride()), edge_index.dtype, n, loops, norm)
+    if edge_weight is not None:
+        k += (edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape),
+              edge_weight.dtype)
+    return k
+
+
+def plan_for(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+             add_self_loops: bool = True, normalize: bool = True) -> GraphPlan:
+    key = _key(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        _PLAN_CACHE.move_to_end(key)
+        return hit[0]
+    plan = GraphPlan(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
+    _PLAN_CACHE[key] = (plan, edge_index, edge_weight)
+    while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+        _PLAN_CACHE.popitem(last=False)
+    return plan
+
+
+def clear_plan_cache() -> None:
+    _PLAN_CACHE.clear()

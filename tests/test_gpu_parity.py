@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path, called through the C ABI (pytextgcn_amd -> ctypes -> libtgcn.so),
+against the CPU oracle on identical inputs.  Tolerance is BASELINE.json's: 1e-5 relative fp32,
+measured as max|a-b| / max|b|; index arrays must match exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csr_oracle, gcn_oracle as O
+import pytextgcn_amd as pkg
+from pytextgcn_amd import synth
+from pytextgcn_amd.plan import GraphPlan, colsum
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def oracle_spmm(ei, w, n, x, bias=None, transpose=False, add_self_loops=True, normalize=True):
+    ei, w = ei.cpu(), None if w is None else w.cpu()
+    if normalize:
+        nei, nw = O.gcn_norm(ei, w, n, add_self_loops)
+    else:
+        nei, nw = ei, (torch.ones(ei.size(1)) if w is None else w)
+    if transpose:
+        nei = nei.flip(0)
+    out = O.propagate(nei, x.cpu(), nw, n)
+    return out if bias is None else out + bias.cpu()
+
+
+# ------------------------------------------------------------------------------------------------
+# plan: normalisation + CSR
+# ------------------------------------------------------------------------------------------------
+def test_known_answer_vector(cuda):
+    z = np.load(os.path.join(GOLD, "known_answer.npz"))
+    ei = torch.from_numpy(z["edge_index"]).to(cuda)
+    w = torch.from_numpy(z["edge_weight"]).to(cuda)
+    plan = GraphPlan(ei, w, 3)
+    assert plan.nnz == 7 and not plan.symmetric
+    rp, col, val = plan.export_csr()
+    assert rp.tolist() == [0, 2, 5, 7] and col.tolist() == [0, 1, 0, 1, 2, 1, 2]
+    exp = torch.tensor([.25, .8320503, .5547002, .3076923, .1132277, .2264554, .6666666])
+    assert torch.allclose(val.cpu(), exp, atol=1e-6)
+    W, b = torch.from_numpy(z["W"]).to(cuda), torch.from_numpy(z["b"]).to(cuda)
+    out = plan.spmm(W, b)
+    assert rel_err(out, torch.from_numpy(z["out"])) < TOL
+    dW = plan.spmm(torch.from_numpy(z["dout"]).to(cuda), transpose=True)
+    assert rel_err(dW, torch.from_numpy(z["dW"])) < TOL
+
+
+@pytest.mark.parametrize("seed,n,e,loops,dups,weighted,add_loops,normalize", [
+    (0, 1, 0, 0, 0, True, True, True), (1, 7, 20, 0, 0, True, True, True),
+    (2, 333, 4000, 15, 40, True, True, True), (3, 640, 5000, 8, 20, False, True, True),
+    (4, 400, 1500, 6, 5, True, False, True), (5, 640, 400, 0, 0, True, False, True),
+    (6, 500, 3000, 5, 5, True, True, False), (7, 500, 3000, 5, 5, False, False, False),
+])
+def test_plan_matches_gcn_norm(cuda, seed, n, e, loops, dups, weighted, add_loops, normalize):
+    g = synth.random_graph(n, e, seed=seed, self_loops=loops, duplicates=dups, weighted=weighted)
+    ei, w = g.edge_index, g.edge_attr
+    plan = GraphPlan(ei.to(cuda), None if w is None else w.to(cuda), n, add_loops, normalize)
+    if normalize:
+        tgt, src, nw = O.normalized_coo(ei, w, n, add_loops)
+    else:
+        tgt, src, nw = ei[1], ei[0], (torch.ones(ei.size(1)) if w is None else w)
+    for transpose in (False, True):
+        a, b = (src, tgt) if transpose else (tgt, src)
+        # oracle order: sorted by (row, col), ties in edge order -- the order the plan documents
+        order = torch.argsort(a * n + b, stable=True)
+        counts = torch.bincount(a, minlength=n)
+        rp_ref = torch.zeros(n + 1, dtype=torch.int64)
+        rp_ref[1:] = counts.cumsum(0)
+        rp, col, val = plan.export_csr(transpose)
+        assert torch.equal(rp.cpu().long(), rp_ref)
+        assert torch.equal(col.cpu().long(), b[order])
+        assert rel_err(val, nw[order]) < 2e-6
+    assert plan.symmetric is False or e == 0
+
+
+def test_symmetric_graph_is_detected_and_shares_one_copy(cuda):
+    g = synth.word_doc_graph(2000, 24000, seed=2, device=cuda)
+    plan = GraphPlan(g.edge_index, g.edge_attr, 2000)
+    assert plan.symmetric and plan.nnz == 24000 + 2000
+    x = torch.randn(2000, 64, device=cuda)
+    assert torch.equal(plan.spmm(x), plan.spmm(x, transpose=True))
+
+
+# ------------------------------------------------------------------------------------------------
+# SpMM forward / transposed, all kernel paths
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("F", [1, 3, 4, 8, 64, 200, 219, 256, 260, 520])
+def test_spmm_widths(cuda, F):
+    g = synth.random_graph(700, 9000, seed=F, self_loops=9, duplicates=17)
+    ei, w = g.edge_index.to(cuda), g.edge_attr.to(cuda)
+    plan = GraphPlan(ei, w, 700)
+    x = torch.randn(700, F, device=cuda)
+    b = torch.randn(F, device=cuda)
+    assert rel_err(plan.spmm(x, b), oracle_spmm(ei, w, 700, x, b)) < TOL
+    assert rel_err(plan.spmm(x, None, transpose=True), oracle_spmm(ei, w, 700, x, transpose=True)) < TOL
+
+
+def test_spmm_strided_operands_and_noncontiguous_edge_index(cuda):
+    g = synth.word_doc_graph(1500, 20000, seed=8, device=cuda)
+    assert g.edge_index.stride() == (1, 2)                      # coo.T view, text2graph.py:192
+    plan = GraphPlan(g.edge_index, g.edge_attr, 1500)
+    big = torch.randn(1500, 300, device=cuda)
+    x = big[:, 20:220]                                          # ldx = 300, 16-byte aligned offset
+    ref = oracle_spmm(g.edge_index, g.edge_attr, 1500, x.contiguous())
+    assert rel_err(plan.spmm(x), ref) < TOL
+    x2 = big[:, 1:201]                                          # misaligned -> scalar-lane kernel
+    assert rel_err(plan.spmm(x2), oracle_spmm(g.edge_index, g.edge_attr, 1500, x2.contiguous())) < TOL
+    out = torch.full((1500, 260), 7.0, device=cuda)
+    plan.spmm(x, out=out[:, 4:204])
+    assert rel_err(out[:, 4:204], ref) < TOL and (out[:, :4] == 7).all() and (out[:, 204:] == 7).all()
+
+
+@pytest.mark.parametrize("F", [200, 64, 7])
+def test_long_rows_are_split_and_reduced(cuda, F):
+    # a hub of degree 5000 >> item weight (512) plus one of exactly 512/513, among short rows
+    n = 6000
+    hub = torch.arange(1, 5001)
+    src = torch.cat([hub, torch.zeros(5000, dtype=torch.long), torch.arange(1000, 1513),
+                     torch.arange(2000, 2512)])
+    dst = torch.cat([torch.zeros(5000, dtype=torch.long), hub, torch.full((513,), 5500),
+                     torch.full((512,), 5501)])
+    g = torch.Generator().manual_seed(1)
+    extra = torch.randint(0, n, (2, 20000), generator=g)
+    ei = torch.cat([torch.stack([src, dst]), extra], 1).to(cuda)
+    w = (torch.rand(ei.size(1), generator=g) + 0.1).to(cuda)
+    plan = GraphPlan(ei, w, n)
+    st = plan.stats()
+    assert st["long_rows"] >= 2 and st["segments"] >= 12
+    assert not plan.symmetric and plan.query(pkg._lib.Q_LONG_ROWS_T) >= 1
+    x = torch.randn(n, F, device=cuda)
+    b = torch.randn(F, device=cuda)
+    assert rel_err(plan.spmm(x, b), oracle_spmm(ei, w, n, x, b)) < TOL
+    assert rel_err(plan.spmm(x, transpose=True), oracle_spmm(ei, w, n, x, transpose=True)) < TOL
+
+
+def test_empty_rows_get_bias_only(cuda):
+    n = 1000
+    ei = torch.tensor([[5, 6, 7, 900], [10, 10, 500, 999]], device=cuda)     # most rows empty
+    plan = GraphPlan(ei, None, n, add_self_loops=False)
+    x = torch.randn(n, 12, device=cuda)
+    b = torch.randn(12, device=cuda)
+    out = plan.spmm(x, b)
+    ref = oracle_spmm(ei, None, n, x, b, add_self_loops=False)
+    assert rel_err(out, ref) < TOL
+    assert torch.equal(out[0], b) and torch.equal(out[998], b)
+    plan0 = GraphPlan(torch.zeros(2, 0, dtype=torch.long, device=cuda), None, 50, add_self_loops=False)
+    assert plan0.nnz == 0 and torch.equal(plan0.spmm(x[:50], b), b.expand(50, 12))
+
+
+def test_results_are_bitwise_reproducible(cuda):
+    g = synth.word_doc_graph(20000, 400000, seed=3, device=cuda)
+    plan = GraphPlan(g.edge_index, g.edge_attr, 20000)
+    x = torch.randn(20000, 200, device=cuda)
+    a = plan.spmm(x)
+    plan2 = GraphPlan(g.edge_index, g.edge_attr, 20000)
+    assert torch.equal(a, plan.spmm(x)) and torch.equal(a, plan2.spmm(x))
+
+
+def test_colsum(cuda):
+    for n, F in [(1, 1), (5, 3), (1000, 200), (4097, 64), (300, 219), (70000, 8)]:
+        gmat = torch.randn(n, F, device=cuda)
+        assert rel_err(colsum(gmat), csr_oracle.colsum(gmat.cpu())) < TOL
+    big = torch.randn(512, 300, device=cuda)
+    assert rel_err(colsum(big[:, 4:204]), big[:, 4:204].double().sum(0).float()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# operator / module level: GCNConv and GCN against the oracle, forward and backward
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["random53", "random53_noloops_unweighted"])
+def test_gcnconv_golden_forward_backward(cuda, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ei = torch.from_numpy(z["edge_index"]).to(cuda)
+    w = torch.from_numpy(z["edge_weight"]).to(cuda) if z["edge_weight"].size else None
+    conv = pkg.GCNConv(z["W"].shape[0], z["W"].shape[1],
+                       add_self_loops=bool(z["add_self_loops"])).to(cuda)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(z["W"]))
+        conv.bias.copy_(torch.from_numpy(z["b"]))
+    x = torch.from_numpy(z["x"]).to(cuda).requires_grad_()
+    out = conv(x, ei, w)
+    out.backward(torch.from_numpy(z["dout"]).to(cuda))
+    for got, key in [(out, "out"), (x.grad, "dx"), (conv.weight.grad, "dW"), (conv.bias.grad, "db")]:
+        assert rel_err(got, torch.from_numpy(z[key])) < TOL, key
+
+
+@pytest.mark.parametrize("sparse_x", [True, False])
+def test_gcn_two_layer_forward_backward_vs_oracle(cuda, sparse_x):
+    N, C, h = 3000, 10, 200
+    g = synth.word_doc_graph(N, 50000, seed=5, n_classes=C)
+    if not sparse_x:
+        g.x = torch.randn(N, 40)
+    fin = g.x.shape[1]
+    torch.manual_seed(1)
+    ref = O.GCNOracle(fin, C, n_hidden_gcn=h, dropout=0.0)
+    mine = pkg.GCN(fin, C, n_hidden_gcn=h, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    ref.train(), mine.train()
+    lo_r = ref(g)
+    lo_m = mine(gd)
+    assert rel_err(lo_m, lo_r) < TOL
+    loss_r = crit(lo_r[g.train_mask], g.y[g.train_mask])
+    loss_m = crit(lo_m[gd.train_mask], gd.y[gd.train_mask])
+    assert abs(loss_m.item() - loss_r.item()) < TOL * abs(loss_r.item())
+    loss_r.backward(), loss_m.backward()
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad, pr.grad) < 5 * TOL, k     # two chained fp32 sums + CE
+
+
+def test_training_steps_track_the_oracle(cuda):
+    # flat_amazon.py:89,99-109: Adam(amsgrad) steps + eval forward, dropout off for determinism
+    N, C = 1200, 5
+    g = synth.word_doc_graph(N, 16000, seed=6, n_classes=C)
+    torch.manual_seed(3)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=32, dropout=0.0)
+    mine = pkg.GCN(N, C, n_hidden_gcn=32, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    o_r = torch.optim.Adam(ref.parameters(), lr=0.05, amsgrad=True)
+    o_m = torch.optim.Adam(mine.parameters(), lr=0.05, amsgrad=True)
+    for step in range(4):
+        l_r, z_r = O.train_step(ref, g, o_r)
+        l_m, z_m = O.train_step(mine, gd, o_m)          # same step function drives both models
+        assert abs(l_m.item() - l_r.item()) < 1e-4 * abs(l_r.item()), step
+        assert rel_err(z_m, z_r) < 1e-3, step           # Adam's 1/sqrt(v) amplifies fp32 noise
+
+
+def test_golden_tiny_textgcn(cuda):
+    z = np.load(os.path.join(GOLD, "tiny_textgcn.npz"))
+    N = int(z["y"].shape[0])
+    ar = torch.arange(N)
+    g = pkg.Data(x=torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N), (N, N)),
+                 edge_index=torch.from_numpy(z["edge_index"]), edge_attr=torch.from_numpy(z["edge_attr"]),
+                 y=torch.from_numpy(z["y"]), train_mask=torch.from_numpy(z["train_mask"])).to(cuda)
+    m = pkg.GCN(N, 3, n_hidden_gcn=8, dropout=0.0)
+    m.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init.")})
+    m = m.to(cuda).float().train()
+    logits = m(g)
+    assert rel_err(logits, torch.from_numpy(z["logits0"])) < TOL
+    loss = torch.nn.CrossEntropyLoss()(logits[g.train_mask], g.y[g.train_mask])
+    assert abs(loss.item() - z["losses"][0]) < TOL * abs(z["losses"][0])
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(z["grad." + k])) < 5 * TOL, k
+
+
+def test_dropout_sits_between_layers_only(cuda):
+    g = synth.word_doc_graph(800, 9000, seed=7, n_classes=4, device=cuda)
+    m = pkg.GCN(800, 4, n_hidden_gcn=16, dropout=0.9).to(cuda)
+    m.eval()
+    a, b = m(g), m(g)
+    assert torch.equal(a, b)
+    m.train()
+    assert not torch.equal(m(g), m(g))
+    l0, l1 = m.layers
+    m.eval()
+    h = l0(g.x, g.edge_index, g.edge_attr)
+    assert (h < 0).any() and torch.equal(l1(h, g.edge_index, g.edge_attr), a)   # no activation
+
+
+def test_error_behaviour(cuda):
+    ei = torch.tensor([[0, 1, 9], [1, 0, 2]], device=cuda)
+    with pytest.raises(IndexError):
+        GraphPlan(ei, None, 5)
+    with pytest.raises(ValueError):
+        GraphPlan(ei[:1], None, 5)
+    with pytest.raises(ValueError):
+        GraphPlan(ei, torch.ones(2, device=cuda), 10)
+    plan = GraphPlan(ei, None, 10)
+    with pytest.raises(ValueError):
+        plan.spmm(torch.ones(9, 4, device=cuda))
+    with pytest.raises(TypeError):
+        plan.spmm(torch.ones(10, 4, device=cuda, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        plan.spmm(torch.ones(10, 4))
+
+
+# ------------------------------------------------------------------------------------------------
+# benchmark-sized inputs (BASELINE.json configs c2 and c4)
+# ------------------------------------------------------------------------------------------------
+def test_config_c2_against_csr_oracle(cuda):
+    N, E, F = 100_000, 2_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    x = torch.randn(N, F, device=cuda)
+    b = torch.randn(F, device=cuda)
+    rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N)
+    assert rel_err(plan.spmm(x, b), csr_oracle.csr_spmm(rp, c, v, x.cpu(), b.cpu(), acc64=True)) < TOL
+    rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N, transpose=True)
+    assert rel_err(plan.spmm(x, transpose=True), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)) < TOL
+
+
+def test_config_c4_full_size_properties_and_sampled_rows(cuda):
+    N, E, F = 2_000_000, 50_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    assert plan.nnz == E + N and plan.symmetric
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    y = torch.randn(N, F, device=cuda, generator=gen)
+    mx, my = plan.spmm(x), plan.spmm(y)
+    # linearity: M(2x - 3y) = 2Mx - 3My
+    lin = plan.spmm(2 * x - 3 * y)
+    assert rel_err(lin, 2 * mx - 3 * my) < TOL
+    # adjointness: <Mx, y> = <x, M^T y>  (transposed path; here M^T = M)
+    lhs = (mx.double() * y.double()).sum().item()
+    rhs = (x.double() * plan.spmm(y, transpose=True).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3
+    # M applied to constant columns = row sums of M, checked against the exported CSR
+    rp, col, val = plan.export_csr()
+    rowsum = torch.zeros(N, device=cuda, dtype=torch.float64)
+    rows = torch.repeat_interleave(torch.arange(N, device=cuda), (rp[1:] - rp[:-1]).long())
+    rowsum.index_add_(0, rows, val.double())
+    ones = plan.spmm(torch.ones(N, 4, device=cuda))
+    assert rel_err(ones[:, 0], rowsum.float()) < TOL
+    # sampled rows (the heaviest word rows and random ones) against a float64 gather on the GPU
+    deg = (rp[1:] - rp[:-1]).long()
+    sample = torch.cat([deg.topk(8).indices, torch.randint(0, N, (200,), device=cuda, generator=gen)])
+    for r in sample.tolist():
+        s, e = rp[r].item(), rp[r + 1].item()
+        ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
+        assert rel_err(mx[r], ref.float()) < TOL, r
+    del rows, rowsum
+
+
+def test_config_c4_row_block_against_reference_formulation(cuda):
+    """Rows [0, 60 000) of the c4 operator (all word rows up to 1.3 M non-zeros each, ~10 M
+    non-zeros in total) against the C CSR oracle on the host."""
+    N, E, F = 2_000_000, 50_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    R = 60_000
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    out = plan.spmm(x)[:R].cpu()
+    rp, col, val = plan.export_csr()
+    nn_ = rp[R].item()
+    ref = csr_oracle.csr_spmm(rp[:R + 1].cpu().long(), col[:nn_].cpu(), val[:nn_].cpu(), x.cpu(),
+                              acc64=True)
+    assert rel_err(out, ref) < TOL

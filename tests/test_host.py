@@ -1,0 +1,85 @@
+"""Host-side logic that needs no GPU: the Data container, the synthetic graph generator, the
+module surface mirrored from the reference, and the loud failure of the product path on CPU."""
+import pickle
+
+import pytest
+import torch
+
+import pytextgcn_amd as pkg
+from pytextgcn_amd import synth
+from pytextgcn_amd.data import Data
+
+
+def test_data_container_surface():
+    d = Data(x=torch.eye(3), edge_index=torch.zeros(2, 4, dtype=torch.long), edge_attr=torch.ones(4),
+             y=torch.arange(3), train_mask=torch.tensor([True, False, True]), n_vocab=2)
+    assert d.num_nodes == 3 and d.num_edges == 4 and d.n_vocab == 2
+    assert "train_mask" in d and set(d.keys) >= {"x", "edge_index", "edge_attr", "y", "n_vocab"}
+    d2 = pickle.loads(pickle.dumps(d))                      # text2graph.py:195-217 save/load
+    assert torch.equal(d2.edge_index, d.edge_index)
+    assert d.to("cpu") is d
+
+
+def test_word_doc_graph_shape_contract():
+    N, E = 3000, 40000
+    g = synth.word_doc_graph(N, E, seed=44, n_classes=7)
+    ei = g.edge_index
+    V = g.n_vocab
+    assert ei.shape == (2, E) and ei.dtype == torch.int64 and ei.stride() == (1, 2)   # coo.T view
+    assert g.edge_attr.shape == (E,) and g.edge_attr.dtype == torch.float32
+    assert (g.edge_attr > 0).all()
+    assert (ei[0] != ei[1]).all()
+    key = ei[0] * N + ei[1]
+    assert key.unique().numel() == E                        # no duplicates
+    rev = ei[1] * N + ei[0]
+    assert torch.equal(key.sort().values, rev.sort().values)            # symmetric structure
+    # both directions carry the same weight
+    o1, o2 = key.argsort(), rev.argsort()
+    assert torch.equal(g.edge_attr[o1], g.edge_attr[o2])
+    ww = (ei[0] < V) & (ei[1] < V)
+    n_ww = int(ww.sum())
+    assert ww[:n_ww].all() and not ww[n_ww:].any()          # word-word block first
+    assert torch.equal(ei[0, :n_ww:2], ei[1, 1:n_ww:2])     # interleaved (i,j),(j,i)
+    half = (E - n_ww) // 2
+    assert (ei[0, n_ww:n_ww + half] >= V).all() and (ei[1, n_ww:n_ww + half] < V).all()
+    assert (ei[0, n_ww + half:] < V).all() and (ei[1, n_ww + half:] >= V).all()
+    assert not ((ei[0] >= V) & (ei[1] >= V)).any()          # no doc-doc edges
+    assert g.x.is_sparse and g.x.shape == (N, N)
+    assert (g.y[:V] == 0).all() and g.y.max() < 7
+    m = g.train_mask.long() + g.val_mask.long() + g.test_mask.long()
+    assert (m[:V] == 0).all() and (m[V:] == 1).all()
+    g2 = synth.word_doc_graph(N, E, seed=44, n_classes=7)
+    assert torch.equal(g2.edge_index, ei) and torch.equal(g2.edge_attr, g.edge_attr)
+
+
+def test_power_law_graph():
+    g = synth.power_law_graph(2000, 30000, seed=1)
+    ei = g.edge_index
+    assert ei.shape == (2, 30000) and (ei[0] != ei[1]).all()
+    assert (ei[0] * 2000 + ei[1]).unique().numel() == 30000
+    deg = torch.bincount(ei[1], minlength=2000)
+    assert deg.max() > 20 * deg.float().mean()              # heavy tail
+
+
+def test_model_surface_matches_reference():
+    m = pkg.models.GCN(50, 4, n_hidden_gcn=16, dropout=0.3)
+    assert sorted(m.state_dict()) == ["layers.0.bias", "layers.0.weight", "layers.1.bias",
+                                      "layers.1.weight"]
+    assert m.layers[0].weight.shape == (50, 16) and m.layers[1].weight.shape == (16, 4)
+    assert (m.layers[0].bias == 0).all()
+    a = (6.0 / (50 + 16)) ** 0.5
+    assert m.layers[0].weight.abs().max() <= a
+    assert isinstance(m.activation, torch.nn.ReLU) and m.dropout == 0.3
+    m3 = pkg.GCN(50, 4, n_gcn=3)
+    assert [tuple(l.weight.shape) for l in m3.layers] == [(50, 64), (64, 64), (64, 4)]
+    m4 = pickle.loads(pickle.dumps(m))                      # th.save(gcn, ...) whole-module pickle
+    assert torch.equal(m4.layers[1].weight, m.layers[1].weight)
+
+
+def test_product_path_has_no_cpu_fallback():
+    g = synth.word_doc_graph(100, 600, seed=1, n_classes=3)
+    m = pkg.GCN(100, 3, n_hidden_gcn=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(g)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.colsum(torch.ones(4, 4))
