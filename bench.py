@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
+
+metric   edges/sec of the forward + backward normalised SpMM pair at width F = h = 200
+         (= 2*E / (t_fwd + t_bwd)), on the synthetic 2 M-node / 50 M-edge
+         PMI / TF-IDF word-document graph (config c4, seed 44), inputs resident in HBM.
+step     one pass of the hot path: out = M @ X + b (GCNConv propagate + bias, layer-1 width) and
+         dXW = M^T @ dOut (its autograd), both through libtgcn.so.
+N > 1    the SAME graph 1-D row-partitioned over N GPUs ("strong" scaling): per SpMM one RCCL
+         all-gather of the row-sharded operand, then the local row block (pytextgcn_amd/sharded.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the CSR gather SpMM, HBM-bound) and `cpu_baseline` (the oracle's reference formulation timed on
+this box's host cores over a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_nodes, n_edges, F, n_classes)
+    "c2": (100_000, 2_000_000, 200, 64),
+    "c4": (2_000_000, 50_000_000, 200, 64),
+}
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
+    p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
+    return p.parse_args()
+
+
+def cpu_baseline(plan, F, frac, seed=44):
+    """Reference formulation (PyG-1.6.3 index_select -> scale -> scatter_add, oracle/gcn_oracle.py
+    `propagate`) on the host cores, over the sub-operator whose TARGET rows are a random `frac`
+    of the nodes (forward) and its transpose (backward).  Bounded sample of the same workload."""
+    from oracle import gcn_oracle as O
+    N = plan.num_nodes
+    gen = torch.Generator().manual_seed(seed)
+    rp, col, val = (t.cpu() for t in plan.export_csr())
+    pick = torch.rand(N, generator=gen) < frac
+    deg = (rp[1:] - rp[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(N), deg)
+    sel = pick[rows]
+    tgt, src, w = rows[sel], col[sel].long(), val[sel]
+    n_edges = int((tgt != src).sum())                       # self-loops are not graph edges
+    x = torch.randn(N, F, generator=gen)
+    fwd = torch.stack([src, tgt])                           # out[tgt] += w * x[src]
+    bwd = torch.stack([tgt, src])                           # dxw[src] += w * g[tgt]
+    times = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        O.propagate(fwd, x, w, N)
+        t1 = time.perf_counter()
+        O.propagate(bwd, x, w, N)
+        t2 = time.perf_counter()
+        if rep:                                             # first repetition is the warm-up
+            times.append((t1 - t0) + (t2 - t1))
+    t = sorted(times)[len(times) // 2]
+    return {"value": 2.0 * n_edges / t, "unit": "edges/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"reference formulation (gather->scale->index_add, fwd+bwd) on the rows of a "
+                      f"random {frac:.4f} of the nodes of the same graph: {n_edges} edges, "
+                      f"{int(sel.sum())} non-zeros, F={F}, median of 2 timed reps, "
+                      f"{t:.2f} s per fwd+bwd pair, os.cpu_count()={os.cpu_count()}"}
+
+
+def measured_traffic(config, n_gpus):
+    """HBM bytes per SpMM launch from rocprofv3 PMC passes (profiles/traffic.json, collected and
+    corrected as MI355X_MICROARCH.md 'HBM' prescribes); None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec.get(f"{config}_n{n_gpus}", {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def epoch_time_ms(g, F, n_classes, reps=3):
+    """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
+    bwd, Adam(amsgrad) step) + eval forward + metric transfer to the host."""
+    import pytextgcn_amd as pkg
+    N = g.y.numel()
+    model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
+    opt = torch.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
+    crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    times = []
+    for rep in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train()
+        out = model(g)[g.train_mask]
+        loss = crit(out, g.y[g.train_mask])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            logits = model(g)
+            crit(logits[g.val_mask], g.y[g.val_mask])
+            pred_val = logits[g.val_mask].argmax(1).cpu().numpy()
+            pred_train = logits[g.train_mask].argmax(1).cpu().numpy()
+        loss.item()
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) * 1e3)
+    del model, opt
+    return sorted(times)[len(times) // 2]
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pytextgcn_amd import synth
+    from pytextgcn_amd.plan import GraphPlan
+
+    N, E, F, C = CONFIGS[args.config]
+    g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C)     # same graph on every rank
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    bias = torch.randn(F, device=dev, generator=gen)
+
+    if world == 1:
+        plan = GraphPlan(g.edge_index, g.edge_attr, N)
+        x = torch.randn(N, F, device=dev, generator=gen)
+        gout = torch.randn(N, F, device=dev, generator=gen)
+        y = torch.empty(N, F, device=dev)
+        dxw = torch.empty(N, F, device=dev)
+
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            plan.spmm(x, bias, out=y)
+            if ev is not None:
+                ev[1].record()
+            plan.spmm(gout, None, transpose=True, out=dxw)
+            if ev is not None:
+                ev[2].record()
+        bytes_fwd = plan.algorithmic_bytes(F, bias=True)
+        bytes_bwd = plan.algorithmic_bytes(F, bias=False, transpose=True)
+        parallelism = "single"
+    else:
+        from pytextgcn_amd.sharded import ShardedGraph
+        sg = ShardedGraph(g.edge_index, g.edge_attr, N, group=dist.group.WORLD)
+        x = torch.randn(sg.n_local, F, device=dev, generator=gen)
+        gout = torch.randn(sg.n_local, F, device=dev, generator=gen)
+
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            sg.spmm(x, bias)
+            if ev is not None:
+                ev[1].record()
+            sg.spmm(gout, None, transpose=True)
+            if ev is not None:
+                ev[2].record()
+        plan = sg.plan
+        bytes_fwd = plan.algorithmic_bytes(F, bias=True)
+        bytes_bwd = plan.algorithmic_bytes(F, bias=False, transpose=True)
+        parallelism = f"row{world}"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # per-launch kernel time of the SpMM op (k_spmm_gather + k_spmm_fix) from HIP events recorded
+    # on the launch stream inside the timed region
+    ms_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    ms_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    launch_ms = 0.5 * (ms_fwd + ms_bwd)
+    launch_bytes = 0.5 * (bytes_fwd + bytes_bwd)
+    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
+
+    epoch_ms = None
+    if world == 1 and not args.no_epoch:
+        del x, gout
+        epoch_ms = epoch_time_ms(g, F, C)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "edges/sec (fwd+bwd SpMM), 2M-node/50M-edge graph h=200"
+                      if args.config == "c4" else f"edges/sec (fwd+bwd SpMM), {args.config}",
+            "value": 2.0 * E / (elapsed / args.steps),
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: synthetic PMI/TF-IDF word-doc graph, N={N}, E={E}, "
+                                   f"nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G",
+                       "parallelism": parallelism},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": measured_traffic(args.config, world),
+                         "kernel": "k_spmm_gather (+k_spmm_fix), one tgcn_spmm launch",
+                         "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
+                         "algorithmic_bytes_per_launch": launch_bytes},
+            "epoch_ms": epoch_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@
  *   - every function returns a status: 0 ok, <0 error (TGCN_E_*); tgcn_last_error() returns a
  *     thread-local, human readable message for the last failing call on this thread.  Nothing
  *     throws, nothing aborts the process.
- *   - compute entry points (tgcn_spmm, tgcn_colsum, tgcn_xw_*) only ENQUEUE on the caller's stream,
+ *   - compute entry points (tgcn_spmm, tgcn_colsum) only ENQUEUE on the caller's stream,
  *     never allocate and never synchronise (hipGraph-capturable).  tgcn_plan_create allocates and
  *     synchronises `stream` (it is a one-off per graph).
  *   - a plan is immutable after creation: safe to share between threads and streams as long as
@@ -60,7 +60,8 @@ const char *tgcn_last_error(void);
  *   dst, dst_stride       non-contiguous view `coo.T` (text2graph.py:192), so strides are honoured
  *   w                     edge_attr (fp32, contiguous) or NULL for all-ones
  *   add_self_loops        GCNConv(add_self_loops=...) -- the reference always passes True
- *   normalize             GCNConv(normalize=...)      -- the reference keeps the default True
+ *   normalize             GCNConv(normalize=...)      -- the reference keeps the default True; as in
+ *                         PyG, loops are added inside gcn_norm, i.e. only when normalize != 0
  *   row_begin, row_end    rows [row_begin,row_end) of M and of M^T that this plan will produce
  *                         (1-D row partition across GPUs); 0, n_nodes for the whole graph.  The
  *                         normalisation is always computed over the WHOLE edge list.

@@ -60,22 +60,25 @@ def propagate(plan: GraphPlan, xw: Tensor, bias: Optional[Tensor]) -> Tensor:
 
 
 # sparse feature matrices that are exactly the identity (text2graph.py:179): X @ W is W itself
-_IDENTITY_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# keyed by id(x) (tensors compare element-wise, so they cannot key a dict); the weakref both
+# validates the entry and removes it when the tensor dies
+_IDENTITY_CACHE: dict = {}
 
 
 def is_sparse_identity(x: Tensor) -> bool:
     if not x.is_sparse:
         return False
-    hit = _IDENTITY_CACHE.get(x)
-    if hit is not None:
-        return hit
+    hit = _IDENTITY_CACHE.get(id(x))
+    if hit is not None and hit[0]() is x:
+        return hit[1]
     ok = False
     if x.size(0) == x.size(1):
         xc = x if x.is_coalesced() else x.coalesce()
         idx, val = xc.indices(), xc.values()
         if val.numel() == x.size(0):
             ok = bool(((idx[0] == idx[1]).all() & (val == 1).all()).item())
-    _IDENTITY_CACHE[x] = ok
+    key = id(x)
+    _IDENTITY_CACHE[key] = (weakref.ref(x, lambda _, k=key: _IDENTITY_CACHE.pop(k, None)), ok)
     return ok
 
 

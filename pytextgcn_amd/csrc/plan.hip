@@ -139,8 +139,10 @@ __global__ void k_deg_inv_sqrt(const int32_t *__restrict__ rowptr, const float *
     }
 }
 
-// w_hat = dis[src] * w * dis[dst] (PyG's left-to-right order); emits the CSR pair array of M and
-// the (src << 32 | dst, w_hat) pairs that are sorted next to give M^T.
+// w_hat = w * (dis[src] * dis[dst]).  PyG evaluates dis[src] * w * dis[dst] left to right, which
+// rounds (i,j) and (j,i) differently; pairing the two degree factors first keeps a symmetric graph
+// bitwise symmetric (so M^T need not be stored) at <= 1 ulp from PyG's value.  Emits the CSR pair
+// array of M and the (src << 32 | dst, w_hat) pairs that are sorted next to give M^T.
 __global__ void k_finalize(const uint64_t *__restrict__ keys, const float *__restrict__ vals,
                            int64_t nnz, const float *__restrict__ dis, int normalize,
                            int2 *__restrict__ cv, uint64_t *__restrict__ keys_t,
@@ -150,7 +152,7 @@ __global__ void k_finalize(const uint64_t *__restrict__ keys, const float *__res
         const uint64_t k = keys[j];
         const uint32_t d = static_cast<uint32_t>(k >> 32), s = static_cast<uint32_t>(k);
         float v = vals[j];
-        if (normalize) v = dis[s] * v * dis[d];
+        if (normalize) v = v * (dis[s] * dis[d]);
         cv[j] = make_int2(static_cast<int>(s), __float_as_int(v));
         keys_t[j] = (static_cast<uint64_t>(s) << 32) | d;
         vals_t[j] = v;
@@ -489,8 +491,9 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64
     plan->n_nodes = n_nodes;
     plan->row_begin = row_begin;
     plan->row_end = row_end;
+    // PyG adds the loops inside gcn_norm, so GCNConv(normalize=False) never sees them
     const int st = plan_create_impl(n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
-                                    add_self_loops != 0, normalize != 0, row_begin, row_end,
+                                    add_self_loops != 0 && normalize != 0, normalize != 0, row_begin, row_end,
                                     static_cast<hipStream_t>(stream), *plan);
     if (st != TGCN_OK) {
         free_block(plan->fwd);
