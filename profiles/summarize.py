@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 CSV output (gpurun_out/prof/...) into the small summaries committed here.
+
+usage: python profiles/summarize.py <round-tag> <stats_dir> [<fetch_dir> <write_dir> [<calib_dir> <calibw_dir>]]
+  stats_dir : rocprofv3 --kernel-trace --stats --output-format csv -d <stats_dir> -- python3 bench.py ...
+  fetch_dir : rocprofv3 --pmc FETCH_SIZE --kernel-trace ... (own pass)
+  write_dir : rocprofv3 --pmc WRITE_SIZE --kernel-trace ... (own pass)
+  calib_dir : rocprofv3 --pmc FETCH_SIZE on profiles/calibrate_fetch.py (known byte count)
+Writes profiles/<tag>_kernel_stats.md and prints a JSON record for profiles/traffic.json.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    name = name.replace("tgcn::(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def kernel_stats(d):
+    f = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    return list(csv.DictReader(open(f)))
+
+
+def trace(d):
+    f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    return list(csv.DictReader(open(f)))
+
+
+def counters(d):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    lines = [f"# rocprofv3 summary, round {tag}", ""]
+    cmd_file = os.path.join(stats_dir, "..", "command.txt")
+    if os.path.exists(cmd_file):
+        lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- "
+                  + open(cmd_file).read().strip() + "`", ""]
+    rows = kernel_stats(stats_dir)
+    lines += ["## `--kernel-trace --stats` (top 15 kernels by total time)", "",
+              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:15]:
+        lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+                     f"{float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
+                     f"{float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
+    for kname in ("k_spmm_gather", "k_spmm_fix"):
+        tr = [r for r in trace(stats_dir) if kname in r["Kernel_Name"]]
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+        lines += ["", f"`{kname}` dispatches: {len(dur)}; durations (us), in launch order:", "",
+                  "`" + " ".join(f"{d:.0f}" for d in dur) + "`"]
+    out = {"tag": tag}
+    if len(sys.argv) >= 5:
+        fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
+        lines += ["", "## PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE, KiB per dispatch", "",
+                  "| kernel | counter | dispatches | mean KiB | min | max |", "|---|---|---|---|---|---|"]
+        for agg in (fe, wr):
+            for (k, c), v in sorted(agg.items()):
+                if "spmm" in k or "colsum" in k:
+                    lines.append(f"| `{k}` | {c} | {len(v)} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} |")
+        out["fetch_kib"] = {k: sum(v) / len(v) for (k, c), v in fe.items() if "spmm" in k}
+        out["write_kib"] = {k: sum(v) / len(v) for (k, c), v in wr.items() if "spmm" in k}
+    if len(sys.argv) >= 7:
+        lines += ["", "## Calibration on a known byte count (profiles/calibrate_fetch.py: permutation "
+                  "operator, N = 4 M, F = 200)", ""]
+        for d in sys.argv[5:7]:
+            for (k, c), v in sorted(counters(d).items()):
+                if "spmm_gather" in k:
+                    lines.append(f"- `{k}` {c}: " + " ".join(f"{x:.0f}" for x in v) + " KiB per dispatch")
+                    out["calib_" + c.lower() + "_kib"] = sum(v) / len(v)
+        log = os.path.join(sys.argv[5], "..", "calib.log")
+        if os.path.exists(log):
+            for ln in open(log):
+                if ln.startswith("known read bytes"):
+                    lines.append("- " + ln.strip())
+    with open(os.path.join(HERE, f"{tag}_kernel_stats.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
