@@ -74,6 +74,15 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges,
                      int64_t row_begin, int64_t row_end,
                      int device, tgcn_stream stream, tgcn_plan **out);
 
+/* tgcn_plan_create_coo -- a plan from explicit triplets M[row[i], col[i]] = val[i] (n_rows x n_cols,
+ * no loops added, no normalisation, duplicates add up).  It has no counterpart in the reference,
+ * which is single-device (flat_amazon.py:84-86): this is what the 1-D partition across GPUs builds
+ * its per-rank local operators from (pytextgcn_amd/sharded.py).  `val` NULL = ones.
+ * with_transpose = 0 keeps only M (tgcn_spmm(transpose=1) then fails with TGCN_E_INVALID). */
+int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                         const int64_t *row, const int64_t *col, const float *val,
+                         int with_transpose, int device, tgcn_stream stream, tgcn_plan **out);
+
 int tgcn_plan_destroy(tgcn_plan *plan);
 
 /* tgcn_plan_query -- integers describing a plan (host pointer `out`). */
@@ -90,7 +99,9 @@ enum {
     TGCN_Q_SEGMENTS = 9,     /* carry rows written per SpMM, forward block                        */
     TGCN_Q_SEGMENTS_T = 10,
     TGCN_Q_DEVICE_BYTES = 11,/* device memory held by the plan                                    */
-    TGCN_Q_ROW_BEGIN = 12
+    TGCN_Q_ROW_BEGIN = 12,
+    TGCN_Q_HAS_TRANSPOSE = 13,/* 0 for a tgcn_plan_create_coo(with_transpose = 0) plan                */
+    TGCN_Q_N_ROWS_T = 14     /* rows of the transposed block (= columns of the forward block)      */
 };
 int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out);
 

@@ -17,7 +17,7 @@ ABI_VERSION = 1
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
 
 (Q_N_NODES, Q_N_ROWS, Q_NNZ, Q_NNZ_T, Q_SYMMETRIC, Q_ITEMS, Q_ITEMS_T, Q_LONG_ROWS, Q_LONG_ROWS_T,
- Q_SEGMENTS, Q_SEGMENTS_T, Q_DEVICE_BYTES, Q_ROW_BEGIN) = range(13)
+ Q_SEGMENTS, Q_SEGMENTS_T, Q_DEVICE_BYTES, Q_ROW_BEGIN, Q_HAS_TRANSPOSE, Q_N_ROWS_T) = range(15)
 
 # name -> (restype, argtypes); tests/test_abi.py checks this table against include/tgcn.h
 SIGNATURES = {
@@ -26,6 +26,8 @@ SIGNATURES = {
     "tgcn_plan_create": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                  c_int, c_int, c_int64, c_int64, c_int, c_void_p,
                                  POINTER(c_void_p)]),
+    "tgcn_plan_create_coo": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_void_p, POINTER(c_void_p)]),
     "tgcn_plan_destroy": (c_int, [c_void_p]),
     "tgcn_plan_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "tgcn_plan_export": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -85,6 +85,7 @@ struct tgcn_plan {
     int64_t row_begin = 0;
     int64_t row_end = 0;
     bool symmetric = false;
+    bool has_transpose = true;
     tgcn::CsrBlock fwd;
     tgcn::CsrBlock bwd;  // unused when symmetric
 };

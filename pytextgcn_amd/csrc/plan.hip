@@ -60,12 +60,13 @@ inline int grid_for(int64_t n, int per_block = kThreads, int cap = 1 << 20) {
 
 // flags[0] = index out of range seen; flags[1] = number of self-loop edges in the input
 __global__ void k_scan_edges(int64_t E, const int64_t *__restrict__ src, int64_t ss,
-                             const int64_t *__restrict__ dst, int64_t ds, int64_t N, int add_loops,
+                             const int64_t *__restrict__ dst, int64_t ds, int64_t n_rows,
+                             int64_t n_cols, int add_loops,
                              unsigned long long *__restrict__ loop_eid, unsigned int *flags) {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
         const int64_t s = src[e * ss], d = dst[e * ds];
-        if (s < 0 || s >= N || d < 0 || d >= N) {
+        if (s < 0 || s >= n_cols || d < 0 || d >= n_rows) {
             flags[0] = 1u;
             continue;
         }
@@ -81,7 +82,7 @@ __global__ void k_scan_edges(int64_t E, const int64_t *__restrict__ src, int64_t
 // key N << 32 so they sort behind every real row.
 __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t ss,
                             const int64_t *__restrict__ dst, int64_t ds,
-                            const float *__restrict__ w, int64_t N, int add_loops,
+                            const float *__restrict__ w, int64_t N, int64_t n_cols, int add_loops,
                             const unsigned long long *__restrict__ loop_eid,
                             uint64_t *__restrict__ keys, float *__restrict__ vals) {
     const int64_t total = E + (add_loops ? N : 0);
@@ -90,7 +91,7 @@ __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t 
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
         if (i < E) {
             const int64_t s = src[i * ss], d = dst[i * ds];
-            const bool bad = s < 0 || s >= N || d < 0 || d >= N;
+            const bool bad = s < 0 || s >= n_cols || d < 0 || d >= N;
             keys[i] = (bad || (add_loops && s == d))
                           ? drop
                           : (static_cast<uint64_t>(d) << 32) | static_cast<uint64_t>(s);
@@ -311,13 +312,18 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
 
 namespace {
 
-int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const int64_t *dst,
-                     int64_t ds, const float *w, int add_loops, int normalize, int64_t row_begin,
-                     int64_t row_end, hipStream_t stream, tgcn_plan &plan) {
+// Builds the operator with entries M[dst, src] (n_rows x n_cols; square with N = n_rows = n_cols
+// whenever add_loops / normalize are set).  `with_transpose` = 0 skips M^T entirely.
+int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *src, int64_t ss,
+                     const int64_t *dst, int64_t ds, const float *w, int add_loops, int normalize,
+                     int with_transpose, int64_t row_begin, int64_t row_end, hipStream_t stream,
+                     tgcn_plan &plan) {
+    const int64_t N = n_rows;  // the square case below reads naturally with N
     const int64_t total = E + (add_loops ? N : 0);
-    if (N >= (int64_t(1) << 31) - 1 || total >= (int64_t(1) << 31) - 1) {
-        set_error("n_nodes=%lld / n_edges=%lld exceed the int32 index range of this build",
-                  (long long)N, (long long)E);
+    if (n_rows >= (int64_t(1) << 31) - 1 || n_cols >= (int64_t(1) << 31) - 1 ||
+        total >= (int64_t(1) << 31) - 1) {
+        set_error("n_rows=%lld / n_cols=%lld / n_edges=%lld exceed the int32 index range of this build",
+                  (long long)n_rows, (long long)n_cols, (long long)E);
         return TGCN_E_RANGE;
     }
 
@@ -329,14 +335,14 @@ int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const
     TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
     TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
     TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
-    TGCN_CHECK(rowptr_t.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(rowptr_t.alloc(sizeof(int32_t) * (n_cols + 1)));
     TGCN_CHECK(dis.alloc(sizeof(float) * N));
     TGCN_HIP_CHECK(hipMemsetAsync(loop_eid.p, 0, loop_eid.bytes ? loop_eid.bytes : 16, stream));
     TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
 
     if (E > 0) {
         k_scan_edges<<<grid_for(E, kThreads, 4096), kThreads, 0, stream>>>(
-            E, src, ss, dst, ds, N, add_loops, loop_eid.as<unsigned long long>(),
+            E, src, ss, dst, ds, n_rows, n_cols, add_loops, loop_eid.as<unsigned long long>(),
             flags.as<unsigned int>());
         TGCN_HIP_CHECK(hipGetLastError());
     }
@@ -344,20 +350,24 @@ int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const
     TGCN_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
     TGCN_HIP_CHECK(hipStreamSynchronize(stream));
     if (h_flags[0]) {
-        set_error("edge_index holds a node id outside [0, %lld)", (long long)N);
+        set_error("an index lies outside the operator: rows [0, %lld), columns [0, %lld)",
+                  (long long)n_rows, (long long)n_cols);
         return TGCN_E_RANGE;
     }
     const int64_t nnz = total - (add_loops ? int64_t(h_flags[1]) : 0);
 
     if (total > 0) {
         k_make_keys<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
-            E, src, ss, dst, ds, w, N, add_loops, loop_eid.as<unsigned long long>(),
+            E, src, ss, dst, ds, w, n_rows, n_cols, add_loops, loop_eid.as<unsigned long long>(),
             keys_a.as<uint64_t>(), vals_a.as<float>());
         TGCN_HIP_CHECK(hipGetLastError());
     }
     unsigned node_bits = 1;
     while ((int64_t(1) << node_bits) <= N) ++node_bits;  // the drop key N << 32 must sort too
     const unsigned end_bit = 32 + node_bits;
+    unsigned col_bits = 1;
+    while ((int64_t(1) << col_bits) <= n_cols) ++col_bits;
+    const unsigned end_bit_t = 32 + col_bits;
     // stable: duplicate (dst, src) pairs keep their edge order, so sums are deterministic
     TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
                           vals_b.as<float>(), total, end_bit, stream));
@@ -378,25 +388,32 @@ int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const
             cv.as<int2>(), keys_a.as<uint64_t>(), vals_a.as<float>());
         TGCN_HIP_CHECK(hipGetLastError());
     }
-    // transposed operator: sort by (src, dst)
-    TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
-                          vals_b.as<float>(), nnz, end_bit, stream));
-    k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), nnz, N,
-                                                       rowptr_t.as<int32_t>());
-    TGCN_HIP_CHECK(hipGetLastError());
-    if (nnz > 0) {
-        k_unpack<<<grid_for(nnz, kThreads, 8192), kThreads, 0, stream>>>(
-            keys_b.as<uint64_t>(), vals_b.as<float>(), nnz, cv_t.as<int2>());
+    plan.symmetric = false;
+    plan.has_transpose = with_transpose != 0;
+    if (with_transpose) {
+        // transposed operator: sort by (src, dst)
+        TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
+                              vals_b.as<float>(), nnz, end_bit_t, stream));
+        k_rowptr<<<grid_for(n_cols + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), nnz, n_cols,
+                                                                rowptr_t.as<int32_t>());
         TGCN_HIP_CHECK(hipGetLastError());
+        if (nnz > 0) {
+            k_unpack<<<grid_for(nnz, kThreads, 8192), kThreads, 0, stream>>>(
+                keys_b.as<uint64_t>(), vals_b.as<float>(), nnz, cv_t.as<int2>());
+            TGCN_HIP_CHECK(hipGetLastError());
+        }
+        if (n_rows == n_cols) {
+            TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
+            k_compare<<<grid_for(std::max<int64_t>(nnz, N + 1), kThreads, 4096), kThreads, 0,
+                        stream>>>(rowptr.as<int32_t>(), rowptr_t.as<int32_t>(), N + 1, cv.as<int2>(),
+                                  cv_t.as<int2>(), nnz, flags.as<unsigned int>());
+            TGCN_HIP_CHECK(hipGetLastError());
+            TGCN_HIP_CHECK(
+                hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+            TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+            plan.symmetric = h_flags[0] == 0;
+        }
     }
-    TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
-    k_compare<<<grid_for(std::max<int64_t>(nnz, N + 1), kThreads, 4096), kThreads, 0, stream>>>(
-        rowptr.as<int32_t>(), rowptr_t.as<int32_t>(), N + 1, cv.as<int2>(), cv_t.as<int2>(), nnz,
-        flags.as<unsigned int>());
-    TGCN_HIP_CHECK(hipGetLastError());
-    TGCN_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
-    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
-    plan.symmetric = h_flags[0] == 0;
 
     // sort scratch is no longer needed: release it before the blocks are copied out
     (void)hipFree(keys_a.release());
@@ -407,8 +424,8 @@ int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const
     const int T = item_weight_from_env();
     const bool whole = row_begin == 0 && row_end == N;
     if (whole) {
-        plan.fwd.n_rows = N;
-        plan.fwd.n_cols = N;
+        plan.fwd.n_rows = n_rows;
+        plan.fwd.n_cols = n_cols;
         plan.fwd.nnz = nnz;
         plan.fwd.bytes = rowptr.bytes + cv.bytes;
         plan.fwd.rowptr = static_cast<int32_t *>(rowptr.release());
@@ -418,10 +435,10 @@ int plan_create_impl(int64_t N, int64_t E, const int64_t *src, int64_t ss, const
                               stream));
     }
     TGCN_CHECK(build_items(plan.fwd, T, stream));
-    if (!plan.symmetric) {
+    if (with_transpose && !plan.symmetric) {
         if (whole) {
-            plan.bwd.n_rows = N;
-            plan.bwd.n_cols = N;
+            plan.bwd.n_rows = n_cols;
+            plan.bwd.n_cols = n_rows;
             plan.bwd.nnz = nnz;
             plan.bwd.bytes = rowptr_t.bytes + cv_t.bytes;
             plan.bwd.rowptr = static_cast<int32_t *>(rowptr_t.release());
@@ -492,9 +509,47 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64
     plan->row_begin = row_begin;
     plan->row_end = row_end;
     // PyG adds the loops inside gcn_norm, so GCNConv(normalize=False) never sees them
-    const int st = plan_create_impl(n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
-                                    add_self_loops != 0 && normalize != 0, normalize != 0, row_begin, row_end,
-                                    static_cast<hipStream_t>(stream), *plan);
+    const int st = plan_create_impl(n_nodes, n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
+                                    add_self_loops != 0 && normalize != 0, normalize != 0, 1,
+                                    row_begin, row_end, static_cast<hipStream_t>(stream), *plan);
+    if (st != TGCN_OK) {
+        free_block(plan->fwd);
+        free_block(plan->bwd);
+        delete plan;
+        return st;
+    }
+    *out = plan;
+    return TGCN_OK;
+}
+
+int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *row,
+                         const int64_t *col, const float *val, int with_transpose, int device,
+                         tgcn_stream stream, tgcn_plan **out) {
+    using namespace tgcn;
+    if (!out) {
+        set_error("tgcn_plan_create_coo: out is NULL");
+        return TGCN_E_INVALID;
+    }
+    *out = nullptr;
+    if (n_rows <= 0 || n_cols <= 0 || nnz < 0 || (nnz > 0 && (!row || !col))) {
+        set_error("tgcn_plan_create_coo: need n_rows, n_cols > 0, nnz >= 0 and non-NULL row/col "
+                  "(n_rows=%lld n_cols=%lld nnz=%lld)", (long long)n_rows, (long long)n_cols,
+                  (long long)nnz);
+        return TGCN_E_INVALID;
+    }
+    DeviceGuard guard;
+    TGCN_CHECK(guard.enter(device));
+    tgcn_plan *plan = new (std::nothrow) tgcn_plan();
+    if (!plan) {
+        set_error("tgcn_plan_create_coo: host allocation failed");
+        return TGCN_E_NOMEM;
+    }
+    plan->device = device;
+    plan->n_nodes = n_cols;
+    plan->row_begin = 0;
+    plan->row_end = n_rows;
+    const int st = plan_create_impl(n_rows, n_cols, nnz, col, 1, row, 1, val, 0, 0, with_transpose,
+                                    0, n_rows, static_cast<hipStream_t>(stream), *plan);
     if (st != TGCN_OK) {
         free_block(plan->fwd);
         free_block(plan->bwd);
@@ -540,6 +595,8 @@ int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out) {
             *out = static_cast<int64_t>(f.bytes + (plan->symmetric ? 0 : plan->bwd.bytes));
             break;
         case TGCN_Q_ROW_BEGIN: *out = plan->row_begin; break;
+        case TGCN_Q_HAS_TRANSPOSE: *out = (plan->has_transpose || plan->symmetric) ? 1 : 0; break;
+        case TGCN_Q_N_ROWS_T: *out = t.n_rows; break;
         default:
             set_error("tgcn_plan_query: unknown selector %d", what);
             return TGCN_E_INVALID;
@@ -567,6 +624,10 @@ int tgcn_plan_export(const tgcn_plan *plan, int transpose, int32_t *rowptr, int3
     }
     DeviceGuard guard;
     TGCN_CHECK(guard.enter(plan->device));
+    if (transpose && !plan->symmetric && !plan->has_transpose) {
+        set_error("tgcn_plan_export: this plan was built without its transpose");
+        return TGCN_E_INVALID;
+    }
     const CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rowptr)

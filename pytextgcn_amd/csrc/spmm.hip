@@ -236,6 +236,10 @@ int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx,
                   (long long)ldx, (long long)ldy);
         return TGCN_E_INVALID;
     }
+    if (transpose && !plan->symmetric && !plan->has_transpose) {
+        set_error("tgcn_spmm: transpose requested but the plan was built without it");
+        return TGCN_E_INVALID;
+    }
     const size_t need = tgcn_spmm_workspace_bytes(plan, transpose, F);
     if (need > 0 && (!workspace || workspace_bytes < need)) {
         set_error("tgcn_spmm: workspace of %zu bytes given, %zu needed", workspace_bytes, need);

@@ -59,14 +59,45 @@ class GraphPlan:
                 int(add_self_loops), int(normalize), row_begin, row_end,
                 self.device.index if self.device.index is not None else torch.cuda.current_device(),
                 _stream_ptr(self.device), ctypes.byref(handle)))
+        self._adopt(lib, handle, n_cols=num_nodes, n_cols_t=num_nodes)
+        self.row_begin, self.row_end = int(row_begin), int(row_end)
+
+    def _adopt(self, lib, handle, n_cols: int, n_cols_t: int) -> None:
         self._h = handle
         self._lib = lib
-        self.num_nodes = int(num_nodes)
-        self.row_begin, self.row_end = int(row_begin), int(row_end)
-        self.n_rows = self.row_end - self.row_begin
+        self.num_nodes = int(n_cols)                  # rows of the forward operand X
+        self.n_cols, self.n_cols_t = int(n_cols), int(n_cols_t)
+        self.row_begin, self.row_end = 0, self.query(_lib.Q_N_ROWS)
+        self.n_rows = self.query(_lib.Q_N_ROWS)        # rows of the forward result
+        self.n_rows_t = self.query(_lib.Q_N_ROWS_T)    # rows of the transposed result
         self.nnz = self.query(_lib.Q_NNZ)
         self.nnz_t = self.query(_lib.Q_NNZ_T)
         self.symmetric = bool(self.query(_lib.Q_SYMMETRIC))
+        self.has_transpose = bool(self.query(_lib.Q_HAS_TRANSPOSE))
+
+    @classmethod
+    def from_coo(cls, row: Tensor, col: Tensor, val: Optional[Tensor], n_rows: int, n_cols: int,
+                 with_transpose: bool = False) -> "GraphPlan":
+        """Plan of an explicit n_rows x n_cols operator M[row[i], col[i]] = val[i] (duplicates add
+        up, nothing is normalised): the per-rank local operators of pytextgcn_amd.sharded."""
+        lib = _lib.load()
+        _require_cuda(row, "row")
+        self = cls.__new__(cls)
+        self.device = row.device
+        row = row.long().contiguous()
+        col = col.long().contiguous()
+        if val is not None:
+            val = val.detach().float().contiguous()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.tgcn_plan_create_coo(
+                n_rows, n_cols, row.numel(), row.data_ptr() if row.numel() else None,
+                col.data_ptr() if row.numel() else None,
+                val.data_ptr() if val is not None else None, int(with_transpose),
+                self.device.index if self.device.index is not None else torch.cuda.current_device(),
+                _stream_ptr(self.device), ctypes.byref(handle)))
+        self._adopt(lib, handle, n_cols=n_cols, n_cols_t=n_rows)
+        return self
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -96,11 +127,13 @@ class GraphPlan:
         """SURVEY.md 8(d) / BASELINE.md gather model, unpadded F, no cache reuse assumed:
         nnz*(4 + 4 + 4F) + n_rows*(4 + 4F) (+4F for the bias)."""
         nnz = self.nnz_t if transpose else self.nnz
-        return nnz * (8 + 4 * F) + self.n_rows * (4 + 4 * F) + (4 * F if bias else 0)
+        n_out = self.n_rows_t if transpose else self.n_rows
+        return nnz * (8 + 4 * F) + n_out * (4 + 4 * F) + (4 * F if bias else 0)
 
     def export_csr(self, transpose: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
         nnz = self.nnz_t if transpose else self.nnz
-        rowptr = torch.empty(self.n_rows + 1, dtype=torch.int32, device=self.device)
+        n_out = self.n_rows_t if transpose else self.n_rows
+        rowptr = torch.empty(n_out + 1, dtype=torch.int32, device=self.device)
         col = torch.empty(nnz, dtype=torch.int32, device=self.device)
         val = torch.empty(nnz, dtype=torch.float32, device=self.device)
         _lib.check(self._lib.tgcn_plan_export(self._h, int(transpose), rowptr.data_ptr(),
@@ -115,8 +148,10 @@ class GraphPlan:
         _require_cuda(x, "x")
         if x.dtype != torch.float32 or x.dim() != 2:
             raise TypeError(f"spmm operand must be a 2-D float32 tensor, got {x.dtype} {tuple(x.shape)}")
-        if x.size(0) != self.num_nodes:
-            raise ValueError(f"operand has {x.size(0)} rows, the graph has {self.num_nodes} nodes")
+        need = self.n_cols_t if transpose else self.n_cols
+        if x.size(0) != need:
+            raise ValueError(f"operand has {x.size(0)} rows, the operator has {need} columns")
+        n_out = self.n_rows_t if transpose else self.n_rows
         if x.stride(1) != 1:
             x = x.contiguous()
         F = x.size(1)
@@ -125,8 +160,8 @@ class GraphPlan:
             if bias.numel() != F:
                 raise ValueError(f"bias has {bias.numel()} entries for F={F}")
         if out is None:
-            out = torch.empty(self.n_rows, F, dtype=torch.float32, device=x.device)
-        elif out.shape != (self.n_rows, F) or out.dtype != torch.float32 or out.stride(1) != 1:
+            out = torch.empty(n_out, F, dtype=torch.float32, device=x.device)
+        elif out.shape != (n_out, F) or out.dtype != torch.float32 or out.stride(1) != 1:
             raise ValueError("`out` must be float32 [n_rows, F] with unit column stride")
         ws_bytes = self._lib.tgcn_spmm_workspace_bytes(self._h, int(transpose), F)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None

@@ -1,0 +1,319 @@
+"""1-D row partition of the GCN path across the GPUs of one node (one process per GPU, RCCL).
+
+The reference is single-device (flat_amazon.py:84-86 `gcn.to(device)`, `g.to(device)`; no
+torch.distributed anywhere), so this module has no counterpart to mirror: it partitions the
+SAME arithmetic (GCNConv propagate, textgcn/lib/models.py:20, and its autograd) so that every rank
+owns a block of rows of the operator, of W1 / H1 / logits and of the optimizer state.
+
+Scheme ("Overlap / structure").  Nodes are split into HUBS (replicated operand:
+for a TextGCN graph the V word nodes, whose feature block V x F is small) and REGULAR nodes (the
+documents; their features never leave the owner).  Both classes are dealt to ranks by degree
+(snake order), so every rank gets the same number of rows and of non-zeros.  One SpMM Y = M X is
+
+    all-gather(X_hub shards)            ||  P = A_r @ X_reg(local)      hub rows, partial sums
+    reduce-scatter(P) -> own hub rows   ||  Yb = B_r @ [X_hub ; X_reg(local)] (+ bias)
+    Y_own = [Yb_hub + RS ; Yb_reg]
+
+with two local operators per rank, both built from the globally normalised M:
+    A_r  rows = all hubs, columns = own regular nodes   (entries M[hub, regular in rank r])
+    B_r  rows = own hubs + own regular nodes, columns = all hubs + own regular nodes
+so only 2 x |hubs| x F floats cross xGMI per SpMM instead of N x F, and both collectives overlap
+with a local SpMM.  Edges between regular nodes of different ranks are not representable; with
+`hubs=None` every node is a hub, A_r is empty and the scheme degenerates to the plain
+all-gather of the row-sharded operand.  M^T uses the same operators when M is symmetric (TextGCN
+graphs are, text2graph.py:148-171), otherwise a second pair is built from M^T.
+
+Local layout on every rank: rows [0, hp) = own hub shard, rows [hp, hp + rp) = own regular shard
+(`owned` maps them to global node ids, -1 = padding row).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .conv import glorot_
+
+
+# --------------------------------------------------------------------------------------------------
+# local-operator engine: the HIP library.  (tests inject a CPU engine built on the oracle to run the
+# partition + exchange logic under gloo without a GPU; the package itself ships no CPU engine.)
+# --------------------------------------------------------------------------------------------------
+class HipEngine:
+    def normalized_triplets(self, edge_index, edge_weight, num_nodes, add_self_loops, normalize,
+                            transpose) -> Tuple[Tensor, Tensor, Tensor, bool]:
+        """(row, col, val, symmetric) of M (or M^T), globally normalised, in CSR order."""
+        from .plan import GraphPlan
+        plan = GraphPlan(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
+        rp, col, val = plan.export_csr(transpose)
+        counts = (rp[1:] - rp[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(num_nodes, device=rp.device), counts)
+        sym = plan.symmetric
+        plan.close()
+        return row, col.long(), val, sym
+
+    def make_op(self, row, col, val, n_rows, n_cols):
+        from .plan import GraphPlan
+        return GraphPlan.from_coo(row, col, val, n_rows, n_cols, with_transpose=False)
+
+    def colsum(self, g: Tensor) -> Tensor:
+        from .plan import colsum
+        return colsum(g)
+
+
+class Partition:
+    """Node -> (owner rank, slot) assignment; a pure function of (graph, world, hubs), so every
+    rank computes the same one without communication."""
+
+    def __init__(self, edge_index: Tensor, num_nodes: int, world: int, hubs: Optional[Tensor]):
+        dev = edge_index.device
+        N = num_nodes
+        self.world, self.n_nodes = world, N
+        if hubs is None:
+            hub_mask = torch.ones(N, dtype=torch.bool, device=dev)
+        elif hubs.dtype == torch.bool:
+            hub_mask = hubs.to(dev)
+        else:
+            hub_mask = torch.zeros(N, dtype=torch.bool, device=dev)
+            hub_mask[hubs.to(dev)] = True
+        self.hub_mask = hub_mask
+        s, t = edge_index[0], edge_index[1]
+        # work a node brings to its owner: a regular node all of its edges (as a column of A_r and as
+        # a row of B_r); a hub only its hub-hub edges (its other entries are computed, as partial
+        # sums, by the ranks that own the regular endpoints)
+        deg_all = torch.bincount(s, minlength=N) + torch.bincount(t, minlength=N)
+        hh = hub_mask[s] & hub_mask[t]
+        deg_hh = torch.bincount(s[hh], minlength=N) + torch.bincount(t[hh], minlength=N)
+        self.owner = torch.empty(N, dtype=torch.int64, device=dev)
+        self.slot = torch.empty(N, dtype=torch.int64, device=dev)
+        sizes = []
+        for mask, deg in ((hub_mask, deg_hh), (~hub_mask, deg_all)):
+            ids = torch.nonzero(mask).flatten()
+            order = ids[torch.argsort(deg[ids], descending=True, stable=True)]
+            p = torch.arange(order.numel(), device=dev)
+            rnd, j = p // world, p % world
+            self.owner[order] = torch.where(rnd % 2 == 0, j, world - 1 - j)    # snake deal
+            self.slot[order] = rnd
+            sizes.append((order.numel() + world - 1) // world)
+        self.hp, self.rp = sizes
+        self.n_local = self.hp + self.rp
+        # column / row numbering of the local operators
+        self.hub_col = self.owner * self.hp + self.slot                # valid where hub_mask
+        self.reg_col = world * self.hp + self.slot                     # valid where ~hub_mask
+        # regular-regular edges must be rank-local
+        rr = (~hub_mask[s]) & (~hub_mask[t]) & (self.owner[s] != self.owner[t])
+        if bool(rr.any()):
+            raise ValueError(
+                f"{int(rr.sum())} edges join regular (non-hub) nodes owned by different ranks; "
+                "enlarge `hubs` (hubs=None replicates every node: plain all-gather partition)")
+
+    def owned(self, rank: int) -> Tensor:
+        """Global node id of every local row of `rank` (-1 for padding rows)."""
+        out = torch.full((self.n_local,), -1, dtype=torch.int64, device=self.owner.device)
+        mine = self.owner == rank
+        hub = torch.nonzero(mine & self.hub_mask).flatten()
+        reg = torch.nonzero(mine & ~self.hub_mask).flatten()
+        out[self.slot[hub]] = hub
+        out[self.hp + self.slot[reg]] = reg
+        return out
+
+
+class ShardedGraph:
+    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+                 group=None, hubs: Optional[Tensor] = None, add_self_loops: bool = True,
+                 normalize: bool = True, engine=None):
+        self.group = group if group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        self.engine = engine if engine is not None else HipEngine()
+        self.num_nodes = num_nodes
+        self.device = edge_index.device
+        part = Partition(edge_index, num_nodes, self.world, hubs)
+        self.part = part
+        self.hp, self.rp, self.n_local = part.hp, part.rp, part.n_local
+        self.owned = part.owned(self.rank)
+        self.real = self.owned >= 0
+        row, col, val, sym = self.engine.normalized_triplets(
+            edge_index, edge_weight, num_nodes, add_self_loops, normalize, False)
+        self.symmetric = bool(sym)
+        self.ops = [self._local_ops(row, col, val)]
+        if not self.symmetric:
+            row, col, val, _ = self.engine.normalized_triplets(
+                edge_index, edge_weight, num_nodes, add_self_loops, normalize, True)
+            self.ops.append(self._local_ops(row, col, val))
+        del row, col, val
+        self.plan = self.ops[0][1]            # the larger local operator (for reporting)
+        self._xbuf = {}
+
+    # ---- construction ---------------------------------------------------------------------------
+    def _local_ops(self, t: Tensor, s: Tensor, w: Tensor):
+        """A_r and B_r from the global triplets M[t, s] = w."""
+        p, r, W, hp, rp = self.part, self.rank, self.world, self.hp, self.rp
+        t_hub, s_hub = p.hub_mask[t], p.hub_mask[s]
+        t_mine, s_mine = p.owner[t] == r, p.owner[s] == r
+        # A: hub rows (gathered numbering) <- own regular columns
+        a = t_hub & ~s_hub & s_mine
+        A = None
+        if rp > 0:
+            A = self.engine.make_op(p.hub_col[t[a]], p.slot[s[a]], w[a], W * hp, rp)
+        # B: own rows <- all hubs + own regular columns (hub <- regular entries all live in A)
+        b = t_mine & (s_hub | (s_mine & ~t_hub))
+        tb, sb = t[b], s[b]
+        brow = torch.where(p.hub_mask[tb], p.slot[tb], hp + p.slot[tb])
+        bcol = torch.where(p.hub_mask[sb], p.hub_col[sb], p.reg_col[sb])
+        B = self.engine.make_op(brow, bcol, w[b], hp + rp, W * hp + rp)
+        return A, B
+
+    # ---- data movement ---------------------------------------------------------------------------
+    def scatter_rows(self, full: Tensor) -> Tensor:
+        """Rows of a replicated [N, ...] tensor that this rank owns, in local order (padding rows
+        are zero / False)."""
+        out = torch.zeros((self.n_local,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+        out[self.real] = full[self.owned[self.real]]
+        return out
+
+    def gather_rows(self, local: Tensor) -> Tensor:
+        """Inverse of scatter_rows: the full [N, ...] tensor on every rank (metrics, checkpoints)."""
+        parts = [torch.empty_like(local) for _ in range(self.world)]
+        dist.all_gather(parts, local.contiguous(), group=self.group)
+        full = torch.zeros((self.num_nodes,) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device)
+        for q in range(self.world):
+            own = self.part.owned(q)
+            real = own >= 0
+            full[own[real]] = parts[q][real]
+        return full
+
+    # ---- the distributed SpMM --------------------------------------------------------------------
+    def spmm(self, x_local: Tensor, bias: Optional[Tensor] = None, transpose: bool = False) -> Tensor:
+        A, B = self.ops[1 if (transpose and not self.symmetric) else 0]
+        W, hp, rp = self.world, self.hp, self.rp
+        if x_local.shape[0] != self.n_local:
+            raise ValueError(f"operand has {x_local.shape[0]} rows, this rank owns {self.n_local}")
+        x_local = x_local.contiguous()
+        F = x_local.size(1)
+        key = (F, x_local.dtype)
+        xbuf = self._xbuf.get(key)
+        if xbuf is None:
+            xbuf = torch.empty(W * hp + rp, F, dtype=x_local.dtype, device=x_local.device)
+            self._xbuf = {key: xbuf}
+        if hp == 0:
+            raise ValueError("a sharded graph needs at least one hub node per rank")
+        ag = dist.all_gather_into_tensor(xbuf[:W * hp], x_local[:hp], group=self.group, async_op=True)
+        rs = rs_out = None
+        if A is not None:
+            xbuf[W * hp:].copy_(x_local[hp:])
+            partial = A.spmm(x_local[hp:])                       # overlaps the all-gather
+            ag.wait()
+            rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
+            rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
+        else:
+            ag.wait()
+        y = B.spmm(xbuf, bias)                                   # overlaps the reduce-scatter
+        if rs is not None:
+            rs.wait()
+            y[:hp] += rs_out
+        return y
+
+    def colsum_real(self, g_local: Tensor) -> Tensor:
+        """Column sums over this rank's real rows (padding rows carry zero gradient by
+        construction, but are masked anyway)."""
+        return self.engine.colsum(g_local * self.real.unsqueeze(1).to(g_local.dtype))
+
+    def allreduce_(self, tensors: List[Tensor]) -> None:
+        """Sum small replicated tensors (W2, b1, b2 gradients, loss terms) in ONE flat all-reduce."""
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, group=self.group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class _ShardedPropagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor]):
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        return sg.spmm(xw_local.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        sg = ctx.sg
+        g = grad_out.contiguous()
+        d_xw = sg.spmm(g, None, transpose=True) if ctx.needs_input_grad[1] else None
+        d_bias = sg.colsum_real(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return None, d_xw, d_bias
+
+
+def sharded_propagate(sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor]) -> Tensor:
+    return _ShardedPropagate.apply(sg, xw_local, bias)
+
+
+class ShardedGCN(nn.Module):
+    """The GCN of textgcn/lib/models.py:6-25 for one-hot features (text2graph.py:179: X = I, so
+    X @ W1 = W1), with W1 row-sharded like the graph: `layers_w[0]` is [n_local, hidden].  The
+    small dense parameters (b1, W2, b2, ...) are replicated; `sync_grads()` sums their gradients
+    over ranks after backward (W1's gradient rows are owned and need no reduction)."""
+
+    def __init__(self, sg: ShardedGraph, in_channels, out_channels, n_gcn=2, n_hidden_gcn=64,
+                 activation=nn.ReLU, dropout=0.5):
+        super().__init__()
+        if in_channels != sg.num_nodes:
+            raise ValueError("ShardedGCN implements the one-hot feature case: in_channels must equal num_nodes")
+        self.sg = sg
+        self.activation = activation()
+        self.dropout = dropout
+        dims = [n_hidden_gcn] * (n_gcn - 1) + [out_channels]
+        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(sg.n_local, dims[0]))])
+        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(dims[0]))])
+        for i in range(1, len(dims)):
+            self.weights.append(nn.Parameter(glorot_(torch.empty(dims[i - 1], dims[i]))))
+            self.biases.append(nn.Parameter(torch.zeros(dims[i])))
+        self.in_channels = in_channels
+
+    def load_full_state_dict(self, sd: dict) -> None:
+        """From a single-device GCN state_dict (`layers.{i}.weight` / `.bias`, PyG-1.6.3 layout)."""
+        with torch.no_grad():
+            for i, (w, b) in enumerate(zip(self.weights, self.biases)):
+                fw = sd[f"layers.{i}.weight"].to(w.device)
+                w.copy_(self.sg.scatter_rows(fw) if i == 0 else fw)
+                b.copy_(sd[f"layers.{i}.bias"].to(b.device))
+
+    def full_state_dict(self) -> dict:
+        sd = {}
+        for i, (w, b) in enumerate(zip(self.weights, self.biases)):
+            sd[f"layers.{i}.weight"] = self.sg.gather_rows(w.detach()) if i == 0 else w.detach().clone()
+            sd[f"layers.{i}.bias"] = b.detach().clone()
+        return sd
+
+    def forward(self, g=None) -> Tensor:
+        """Logits of this rank's rows, [n_local, out_channels] (padding rows hold the bias)."""
+        x = sharded_propagate(self.sg, self.weights[0], self.biases[0])
+        for i in range(1, len(self.weights)):
+            x = nn.functional.dropout(x, p=self.dropout, training=self.training)
+            x = sharded_propagate(self.sg, torch.matmul(x, self.weights[i]), self.biases[i])
+        return x
+
+    def sync_grads(self) -> None:
+        grads = [p.grad for p in list(self.weights)[1:] + list(self.biases) if p.grad is not None]
+        if grads:
+            self.sg.allreduce_(grads)
+
+
+def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tensor,
+                          mask_local: Tensor) -> Tensor:
+    """CrossEntropyLoss(reduction='mean') over the GLOBAL masked rows (flat_amazon.py:82,101-102):
+    local sum of row losses divided by the global row count, so that summing the replicated
+    gradients over ranks reproduces the single-device gradient.  Returns this rank's share of the
+    loss; all-reduce it (sum) for the value the reference prints."""
+    cnt = mask_local.sum().to(torch.float32).reshape(1)
+    dist.all_reduce(cnt, group=sg.group)
+    if bool(mask_local.any()):
+        part = nn.functional.cross_entropy(logits_local[mask_local], y_local[mask_local], reduction="sum")
+    else:
+        part = logits_local.sum() * 0.0
+    return part / cnt.squeeze(0)

@@ -1,0 +1,186 @@
+"""Worker side of tests/test_sharded.py: runs on every rank of a gloo (CPU) process group.  The
+partition / exchange logic under test is pytextgcn_amd.sharded; the per-rank local operators are
+provided by a TEST-ONLY engine built on the CPU oracle (the package ships only the HIP engine)."""
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import csr_oracle, gcn_oracle as O  # noqa: E402
+from pytextgcn_amd import sharded, synth  # noqa: E402
+
+
+class _OracleOp:
+    def __init__(self, row, col, val, n_rows, n_cols):
+        self.n_rows, self.n_cols = n_rows, n_cols
+        self.csr = csr_oracle.coo_to_csr(row, col, val, n_rows)
+
+    def spmm(self, x, bias=None):
+        assert x.shape[0] == self.n_cols
+        return csr_oracle.csr_spmm(*self.csr, x.contiguous(), bias)
+
+
+class OracleEngine:
+    def normalized_triplets(self, edge_index, edge_weight, num_nodes, add_self_loops, normalize, transpose):
+        tgt, src, w = O.normalized_coo(edge_index, edge_weight, num_nodes, add_self_loops)
+        key_a = torch.argsort(tgt * num_nodes + src, stable=True)
+        key_b = torch.argsort(src * num_nodes + tgt, stable=True)
+        sym = bool(torch.equal(tgt[key_a], src[key_b]) and torch.equal(src[key_a], tgt[key_b])
+                   and torch.allclose(w[key_a], w[key_b], rtol=1e-6))
+        if transpose:
+            tgt, src = src, tgt
+        return tgt, src, w, sym
+
+    def make_op(self, row, col, val, n_rows, n_cols):
+        return _OracleOp(row, col, val, n_rows, n_cols)
+
+    def colsum(self, g):
+        return csr_oracle.colsum(g.contiguous())
+
+
+def rel_err(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+def make_graph(kind):
+    if kind == "wordoc":
+        g = synth.word_doc_graph(600, 7000, seed=11, n_classes=5)
+        return g, torch.arange(600) < g.n_vocab
+    if kind == "wordoc_big":          # long hub rows (segments) + F = 200 on the GPU
+        g = synth.word_doc_graph(30000, 600000, seed=14, n_classes=5)
+        return g, torch.arange(30000) < g.n_vocab
+    if kind == "wordoc_allhubs":
+        return synth.word_doc_graph(400, 4000, seed=12, n_classes=5), None
+    if kind == "asym":
+        g = synth.random_graph(300, 2500, seed=13, self_loops=7, duplicates=11)
+        g.y = torch.randint(0, 5, (300,), generator=torch.Generator().manual_seed(1))
+        g.train_mask = torch.rand(300, generator=torch.Generator().manual_seed(2)) < 0.5
+        ar = torch.arange(300)
+        g.x = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(300), (300, 300))
+        return g, None
+    raise ValueError(kind)
+
+
+def check(kind, device="cpu"):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g, hubs = make_graph(kind)
+    N = g.y.numel()
+    if device != "cpu":
+        return check_hip(kind, g, hubs, N, torch.device(device))
+    sg = sharded.ShardedGraph(g.edge_index, g.edge_attr, N, hubs=hubs, engine=OracleEngine())
+    # every node is owned exactly once
+    own = [sg.part.owned(q) for q in range(world)]
+    allids = torch.cat([o[o >= 0] for o in own])
+    assert allids.numel() == N and allids.unique().numel() == N
+    assert sg.symmetric == (kind != "asym")
+    # balance: rows equal by construction, non-zeros within 25 %
+    nnz = torch.tensor([float(sum(op.csr[0][-1].item() for op in sg.ops[0] if op is not None))])
+    lo, hi = nnz.clone(), nnz.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN), dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert hi.item() <= 1.25 * lo.item() + 64, (lo, hi)
+
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 12, generator=gen)
+    b = torch.randn(12, generator=gen)
+    nei, nw = O.gcn_norm(g.edge_index, g.edge_attr, N)
+    for transpose in (False, True):
+        ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N) + b
+        got = sg.gather_rows(sg.spmm(sg.scatter_rows(x), b, transpose=transpose))
+        assert rel_err(got, ref) < 1e-5, (kind, transpose, rel_err(got, ref))
+
+    # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
+    torch.manual_seed(3)
+    ref = O.GCNOracle(N, 5, n_gcn=3, n_hidden_gcn=16, dropout=0.0)
+    mine = sharded.ShardedGCN(sg, N, 5, n_gcn=3, n_hidden_gcn=16, dropout=0.0)
+    mine.load_full_state_dict(ref.state_dict())
+    o_r = torch.optim.Adam(ref.parameters(), lr=0.05, amsgrad=True)
+    o_m = torch.optim.Adam(mine.parameters(), lr=0.05, amsgrad=True)
+    y_l, m_l = sg.scatter_rows(g.y), sg.scatter_rows(g.train_mask)
+    crit = torch.nn.CrossEntropyLoss()
+    for step in range(3):
+        ref.train(), mine.train()
+        lo_r = ref(g)
+        loss_r = crit(lo_r[g.train_mask], g.y[g.train_mask])
+        o_r.zero_grad(set_to_none=True)
+        loss_r.backward()
+        lo_m = mine()
+        loss_m = sharded.sharded_cross_entropy(sg, lo_m, y_l, m_l)
+        o_m.zero_grad(set_to_none=True)
+        loss_m.backward()
+        mine.sync_grads()
+        total = loss_m.detach().clone().reshape(1)
+        dist.all_reduce(total)
+        assert abs(total.item() - loss_r.item()) < 1e-5 * abs(loss_r.item()), (step, total, loss_r)
+        assert rel_err(sg.gather_rows(lo_m.detach()), lo_r.detach()) < 1e-4, step
+        if step == 0:
+            gw1 = sg.gather_rows(mine.weights[0].grad)
+            assert rel_err(gw1, ref.layers[0].weight.grad) < 5e-5
+            for i in (1, 2):
+                assert rel_err(mine.weights[i].grad, ref.layers[i].weight.grad) < 5e-5, i
+            for i in (0, 1, 2):
+                assert rel_err(mine.biases[i].grad, ref.layers[i].bias.grad) < 5e-5, i
+        o_r.step(), o_m.step()
+    sd = mine.full_state_dict()
+    for k, v in ref.state_dict().items():
+        assert rel_err(sd[k], v) < 1e-3, k
+
+
+def check_hip(kind, g, hubs, N, dev):
+    """The same checks with the product engine (libtgcn.so) on a GPU; all ranks may share one card
+    (gloo moves the collectives' payload through the host)."""
+    import pytextgcn_amd as pkg
+    F = 200
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(dev)
+    sg = sharded.ShardedGraph(gd.edge_index, gd.edge_attr, N, hubs=None if hubs is None else hubs.to(dev))
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, F, generator=gen)
+    b = torch.randn(F, generator=gen)
+    nei, nw = O.gcn_norm(g.edge_index, g.edge_attr, N)
+    for transpose in (False, True):
+        ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N) + b
+        got = sg.gather_rows(sg.spmm(sg.scatter_rows(x.to(dev)), b.to(dev), transpose=transpose))
+        assert rel_err(got.cpu(), ref) < 1e-5, (kind, transpose, rel_err(got.cpu(), ref))
+    torch.manual_seed(3)
+    ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
+    mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
+    mine.load_full_state_dict(ref.state_dict())
+    y_l, m_l = sg.scatter_rows(gd.y), sg.scatter_rows(gd.train_mask)
+    lo_r = ref(g)
+    loss_r = torch.nn.CrossEntropyLoss()(lo_r[g.train_mask], g.y[g.train_mask])
+    loss_r.backward()
+    lo_m = mine()
+    loss_m = sharded.sharded_cross_entropy(sg, lo_m, y_l, m_l)
+    loss_m.backward()
+    mine.sync_grads()
+    total = loss_m.detach().clone().reshape(1)
+    dist.all_reduce(total)
+    assert abs(total.item() - loss_r.item()) < 1e-5 * abs(loss_r.item())
+    assert rel_err(sg.gather_rows(lo_m.detach()).cpu(), lo_r.detach()) < 1e-5
+    assert rel_err(sg.gather_rows(mine.weights[0].grad).cpu(), ref.layers[0].weight.grad) < 5e-5
+    assert rel_err(mine.weights[1].grad.cpu(), ref.layers[1].weight.grad) < 5e-5
+    for i in (0, 1):
+        assert rel_err(mine.biases[i].grad.cpu(), ref.layers[i].bias.grad) < 5e-5, i
+
+
+def main(rank, world, port, kinds, errfile, backend="gloo", device="cpu"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    try:
+        if device != "cpu":
+            torch.cuda.set_device(torch.device(device))
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        for kind in kinds:
+            check(kind, device)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        with open(errfile + f".{rank}", "w") as f:
+            f.write(traceback.format_exc())
+        raise
