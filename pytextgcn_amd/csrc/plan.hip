@@ -229,6 +229,67 @@ int take_block(const int32_t *rowptr_full, const int2 *cv_full, int64_t n_nodes,
     return TGCN_OK;
 }
 
+// pos[i * (n_blocks + 1) + j] = first entry of long row i whose column is >= j * col_block
+// (columns are ascending inside a row: the plan is sorted by (row, col)).
+__global__ void k_block_cuts(const int32_t *__restrict__ long_rows, int n_long,
+                             const int32_t *__restrict__ rowptr, const int2 *__restrict__ cv,
+                             int col_block, int n_blocks, int32_t *__restrict__ pos) {
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= int64_t(n_long) * (n_blocks + 1)) return;
+    const int i = static_cast<int>(idx / (n_blocks + 1)), j = static_cast<int>(idx % (n_blocks + 1));
+    const int r = long_rows[i];
+    int lo = rowptr[r], hi = rowptr[r + 1];
+    const int64_t target = int64_t(j) * col_block;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((cv[mid].x & 0x7fffffff) < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    pos[idx] = lo;
+}
+
+// Column reference counts, then the COLD flag (sign bit of the stored column id) on every entry
+// whose column is gathered fewer than `cold_count` times per SpMM: the kernel loads those rows
+// with the non-temporal hint so that they do not push the frequently gathered rows out of L2.
+__global__ void k_col_hist(const int2 *__restrict__ cv, int64_t nnz, int32_t *__restrict__ count) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride)
+        atomicAdd(&count[cv[j].x], 1);
+}
+
+__global__ void k_mark_cold(int2 *__restrict__ cv, int64_t nnz, const int32_t *__restrict__ count,
+                            int cold_count) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
+        const int c = cv[j].x;
+        if (count[c] < cold_count) cv[j].x = c | int(0x80000000u);
+    }
+}
+
+// Tuning knobs (tools/sweep_spmm.py); the defaults are the measured best on config c4.
+struct Knobs {
+    int col_block;  // columns per block for long-row cuts; 0 = no column cuts
+    int min_piece;  // merge adjacent column blocks of a row until a piece has this many entries
+    int order;      // 0 = row order, 1 = segments first, 2 = row blocks first, 3 = interleaved,
+                    // 4 = interleaved in XCD-affine queues (column block j -> XCD j % 8)
+    int cold_count; // columns referenced fewer times than this are gathered non-temporally; 0 = off
+};
+
+Knobs knobs_from_env() {
+    auto geti = [](const char *name, int dflt) {
+        const char *s = std::getenv(name);
+        return s ? std::atoi(s) : dflt;
+    };
+    Knobs k;
+    k.col_block = geti("TGCN_COL_BLOCK", 8192);
+    k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 64));
+    k.order = geti("TGCN_ITEM_ORDER", 3);
+    k.cold_count = geti("TGCN_COLD_COUNT", 0);
+    return k;
+}
+
 int item_weight_from_env() {
     const char *s = std::getenv("TGCN_ITEM_WEIGHT");
     int v = s ? std::atoi(s) : 0;
@@ -246,51 +307,199 @@ void free_block(CsrBlock &b) {
     b = CsrBlock{};
 }
 
-// Greedy host-side partition (one pass over rowptr, a few ms at 2 M rows):
-//   rows of degree <= T are packed, whole, into blocks of weight ~T (weight of a row = degree + 1:
-//   its gathered rows plus its output row); a row of degree > T is cut into ceil(deg/T) equal
-//   segments whose partial sums a second pass adds up in a fixed order.
+// Host-side work partition (one pass over rowptr, a few ms at 2 M rows).
+//   * rows of degree <= T are packed, whole, into ROW BLOCKS of weight ~T (weight of a row =
+//     degree + 1: its gathered rows plus its output row);
+//   * a row of degree > T is cut into SEGMENTS whose partial sums a second pass adds up in a fixed
+//     order.  Cuts fall on column-block boundaries (blocks of `col_block` columns, adjacent blocks
+//     merged until a piece has >= min_piece entries, pieces > T split evenly), and segments are
+//     LAUNCHED in column-block order: the waves resident at any moment then gather from the same
+//     slice of X, which is fetched from HBM once and re-used from L2 / Infinity Cache by the other
+//     long rows (a hub word row shares its document columns with every other hub row);
+//   * row blocks are spread evenly between the segments in launch order, so cache-friendly and
+//     streaming work overlap in time.
 int build_items(CsrBlock &b, int T, hipStream_t stream) {
+    const Knobs kn = knobs_from_env();
     std::vector<int32_t> rp(static_cast<size_t>(b.n_rows) + 1);
     TGCN_HIP_CHECK(hipMemcpyAsync(rp.data(), b.rowptr, sizeof(int32_t) * rp.size(),
                                   hipMemcpyDeviceToHost, stream));
     TGCN_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<WorkItem> items;
-    std::vector<FixEntry> fix;
-    items.reserve(static_cast<size_t>((b.nnz + b.n_rows) / T + 16));
-    int64_t slots = 0;
-    int32_t r0 = 0;
-    int64_t wsum = 0;
     const int32_t n_rows = static_cast<int32_t>(b.n_rows);
-    for (int32_t r = 0; r < n_rows; ++r) {
-        const int32_t d = rp[r + 1] - rp[r];
-        if (d > T) {
-            if (r > r0) items.push_back({r0, r, rp[r0], rp[r]});
-            const int32_t nseg = (d + T - 1) / T;
-            const int32_t seglen = (d + nseg - 1) / nseg;
-            fix.push_back({r, static_cast<int32_t>(slots), nseg, 0});
-            for (int32_t s = 0; s < nseg; ++s) {
-                const int32_t nb = std::min(rp[r] + s * seglen, rp[r + 1]);
-                const int32_t ne = std::min(nb + seglen, rp[r + 1]);
-                items.push_back({r, -static_cast<int32_t>(slots + s) - 1, nb, ne});
-            }
-            slots += nseg;
-            r0 = r + 1;
-            wsum = 0;
-        } else {
-            wsum += d + 1;
-            if (wsum >= T) {
-                items.push_back({r0, r + 1, rp[r0], rp[r + 1]});
+    if (kn.cold_count > 0 && b.nnz > 0) {
+        DevBuf count;
+        TGCN_CHECK(count.alloc(sizeof(int32_t) * b.n_cols));
+        TGCN_HIP_CHECK(hipMemsetAsync(count.p, 0, sizeof(int32_t) * b.n_cols, stream));
+        k_col_hist<<<grid_for(b.nnz, kThreads, 8192), kThreads, 0, stream>>>(b.cv, b.nnz, count.as<int32_t>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        k_mark_cold<<<grid_for(b.nnz, kThreads, 8192), kThreads, 0, stream>>>(b.cv, b.nnz, count.as<int32_t>(),
+                                                                           kn.cold_count);
+        TGCN_HIP_CHECK(hipGetLastError());
+        TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    // pass 1: row blocks and the list of long rows
+    std::vector<WorkItem> blocks;
+    std::vector<int32_t> long_rows;
+    blocks.reserve(static_cast<size_t>((b.nnz + b.n_rows) / T + 16));
+    {
+        int32_t r0 = 0;
+        int64_t wsum = 0;
+        for (int32_t r = 0; r < n_rows; ++r) {
+            const int32_t d = rp[r + 1] - rp[r];
+            if (d > T) {
+                if (r > r0) blocks.push_back({r0, r, rp[r0], rp[r]});
+                long_rows.push_back(r);
                 r0 = r + 1;
                 wsum = 0;
+            } else {
+                wsum += d + 1;
+                if (wsum >= T) {
+                    blocks.push_back({r0, r + 1, rp[r0], rp[r + 1]});
+                    r0 = r + 1;
+                    wsum = 0;
+                }
             }
         }
+        if (r0 < n_rows) blocks.push_back({r0, n_rows, rp[r0], rp[n_rows]});
     }
-    if (r0 < n_rows) items.push_back({r0, n_rows, rp[r0], rp[n_rows]});
-    if (slots > INT32_MAX || items.size() > size_t(INT32_MAX)) {
+
+    // column-block cut positions of the long rows (binary searches on the device)
+    const int32_t n_long = static_cast<int32_t>(long_rows.size());
+    int32_t n_cb = 0;
+    std::vector<int32_t> cuts;
+    if (n_long > 0 && kn.col_block > 0) {
+        const int64_t nb = (b.n_cols + kn.col_block - 1) / kn.col_block;
+        if (nb > 1 && nb <= 8192 && nb * int64_t(n_long) < (int64_t(1) << 28)) n_cb = static_cast<int32_t>(nb);
+    }
+    if (n_cb > 0) {
+        DevBuf d_rows, d_cuts;
+        const size_t n_cut = static_cast<size_t>(n_long) * (n_cb + 1);
+        TGCN_CHECK(d_rows.alloc(sizeof(int32_t) * n_long));
+        TGCN_CHECK(d_cuts.alloc(sizeof(int32_t) * n_cut));
+        TGCN_HIP_CHECK(hipMemcpyAsync(d_rows.p, long_rows.data(), sizeof(int32_t) * n_long,
+                                      hipMemcpyHostToDevice, stream));
+        k_block_cuts<<<grid_for(static_cast<int64_t>(n_cut)), kThreads, 0, stream>>>(
+            d_rows.as<int32_t>(), n_long, b.rowptr, b.cv, kn.col_block, n_cb, d_cuts.as<int32_t>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        cuts.resize(n_cut);
+        TGCN_HIP_CHECK(hipMemcpyAsync(cuts.data(), d_cuts.p, sizeof(int32_t) * n_cut,
+                                      hipMemcpyDeviceToHost, stream));
+        TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    // pass 2: segments
+    struct Seg {
+        WorkItem it;
+        int32_t key;
+    };
+    std::vector<Seg> segs;
+    std::vector<FixEntry> fix;
+    fix.reserve(n_long);
+    int64_t slots = 0;
+    auto emit_piece = [&](int32_t r, int32_t nb, int32_t ne, int32_t key) {
+        const int32_t d = ne - nb;
+        const int32_t nseg = (d + T - 1) / T;
+        const int32_t seglen = (d + nseg - 1) / nseg;
+        for (int32_t s = 0; s < nseg; ++s) {
+            const int32_t sb = std::min(nb + s * seglen, ne);
+            const int32_t se = std::min(sb + seglen, ne);
+            segs.push_back({{r, -static_cast<int32_t>(slots) - 1, sb, se}, key});
+            ++slots;
+        }
+    };
+    for (int32_t i = 0; i < n_long; ++i) {
+        const int32_t r = long_rows[i];
+        const int64_t slot_begin = slots;
+        if (n_cb > 0) {
+            const int32_t *c = cuts.data() + static_cast<size_t>(i) * (n_cb + 1);
+            int32_t j0 = 0;
+            for (int32_t j = 1; j <= n_cb; ++j) {
+                const bool last = j == n_cb;
+                if (c[j] - c[j0] >= kn.min_piece || (last && c[j] > c[j0])) {
+                    // a short tail joins the previous piece instead of becoming a tiny one
+                    if (last && c[j] - c[j0] < kn.min_piece && !segs.empty() && segs.back().it.row_begin == r &&
+                        slots > slot_begin && (segs.back().it.nnz_end - segs.back().it.nnz_begin) + (c[j] - c[j0]) <= T) {
+                        segs.back().it.nnz_end = c[j];
+                    } else {
+                        emit_piece(r, c[j0], c[j], j0);
+                    }
+                    j0 = j;
+                }
+            }
+        } else {
+            emit_piece(r, rp[r], rp[r + 1], 0);
+        }
+        fix.push_back({r, static_cast<int32_t>(slot_begin), static_cast<int32_t>(slots - slot_begin), 0});
+    }
+    if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) {
         set_error("work partition exceeds int32 limits");
         return TGCN_E_RANGE;
     }
+    if (kn.order != 0)
+        std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.key < y.key; });
+
+    // launch order
+    std::vector<WorkItem> items;
+    items.reserve(blocks.size() + segs.size() + 64);
+    if (kn.order == 4) {
+        // XCD-affine queues.  Workgroups are dealt round-robin over the 8 XCDs (workgroup w runs on
+        // XCD w % 8; observed placement, used for speed only) and a workgroup holds 4 items, so the
+        // item at launch position p lands on XCD (p / 4) % 8.  All segments of column block j go to
+        // queue j % 8: a slice of X is then pulled through the fabric by ONE XCD's L2 and re-used
+        // there by every long row, instead of being fetched once per XCD.  Row blocks fill the
+        // queues up to equal length; short queues are padded with empty items to keep alignment.
+        constexpr int kXcd = 8, kGroup = 4;
+        std::vector<std::vector<WorkItem>> q(kXcd);
+        std::vector<std::vector<WorkItem>> qseg(kXcd);
+        for (const Seg &sg : segs) qseg[sg.key % kXcd].push_back(sg.it);
+        const size_t total = segs.size() + blocks.size();
+        const size_t per_q = (total + kXcd - 1) / kXcd;
+        size_t bi = 0;
+        for (int x = 0; x < kXcd; ++x) {
+            const size_t ns = qseg[x].size();
+            const size_t nb = ns >= per_q ? 0 : std::min(per_q - ns, blocks.size() - bi);
+            // spread this queue's row blocks evenly between its segments
+            size_t si = 0, bj = 0;
+            while (si < ns || bj < nb) {
+                if (bj >= nb || (si < ns && si * nb <= bj * ns))
+                    q[x].push_back(qseg[x][si++]);
+                else
+                    q[x].push_back(blocks[bi + bj++]);
+            }
+            bi += nb;
+        }
+        for (int x = 0; bi < blocks.size(); x = (x + 1) % kXcd) q[x].push_back(blocks[bi++]);
+        size_t longest = 0;
+        for (int x = 0; x < kXcd; ++x) longest = std::max(longest, q[x].size());
+        const WorkItem empty = {0, 0, 0, 0};
+        for (size_t pos = 0; pos < longest; pos += kGroup)
+            for (int x = 0; x < kXcd; ++x)
+                for (size_t k = pos; k < pos + kGroup; ++k) {
+                    if (k < q[x].size())
+                        items.push_back(q[x][k]);
+                    else if (pos + kGroup < longest || x < kXcd - 1)
+                        items.push_back(empty);
+                }
+        while (!items.empty() && items.back().nnz_begin == items.back().nnz_end &&
+               items.back().row_begin == items.back().row_end)
+            items.pop_back();
+    } else if (kn.order == 3) {
+        size_t si = 0, bi = 0;
+        const size_t ns = segs.size(), nb = blocks.size();
+        while (si < ns || bi < nb) {
+            if (bi >= nb || (si < ns && si * nb <= bi * ns))
+                items.push_back(segs[si++].it);
+            else
+                items.push_back(blocks[bi++]);
+        }
+    } else if (kn.order == 2) {
+        items = blocks;
+        for (const Seg &sg : segs) items.push_back(sg.it);
+    } else {
+        for (const Seg &sg : segs) items.push_back(sg.it);
+        items.insert(items.end(), blocks.begin(), blocks.end());
+    }
+
     b.n_items = static_cast<int32_t>(items.size());
     b.n_fix = static_cast<int32_t>(fix.size());
     b.n_segments = static_cast<int32_t>(slots);
@@ -609,7 +818,7 @@ __global__ void k_export(const int2 *__restrict__ cv, int64_t nnz, int32_t *col,
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
         const int2 p = cv[j];
-        if (col) col[j] = p.x;
+        if (col) col[j] = p.x & 0x7fffffff;
         if (val) val[j] = __int_as_float(p.y);
     }
 }

@@ -18,16 +18,29 @@
 //   * row sums stay in registers; a finished row is written once, with the bias added.  Long rows
 //     write one partial per segment into the carry workspace and k_spmm_fix adds them in slot
 //     order (LDS across the 4 waves), so the result is bitwise reproducible.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace tgcn {
 namespace {
+
+typedef float native_f4 __attribute__((ext_vector_type(4)));
 
 template <int VEC>
 struct Vec;
 template <>
 struct Vec<4> {
     using type = float4;
+    static __device__ __forceinline__ type load_nt(const float *p) {
+        const native_f4 v = __builtin_nontemporal_load(reinterpret_cast<const native_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    static __device__ __forceinline__ void store_nt(float *p, const type &a) {
+        native_f4 v = {a.x, a.y, a.z, a.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<native_f4 *>(p));
+    }
     static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
     static __device__ __forceinline__ void fma(type &a, float v, const type &x) {
         a.x = fmaf(v, x.x, a.x);
@@ -42,6 +55,8 @@ struct Vec<4> {
 template <>
 struct Vec<1> {
     using type = float;
+    static __device__ __forceinline__ type load_nt(const float *p) { return __builtin_nontemporal_load(p); }
+    static __device__ __forceinline__ void store_nt(float *p, const type &a) { __builtin_nontemporal_store(a, p); }
     static __device__ __forceinline__ type zero() { return 0.f; }
     static __device__ __forceinline__ void fma(type &a, float v, const type &x) { a = fmaf(v, x, a); }
     static __device__ __forceinline__ type add(const type &a, const type &b) { return a + b; }
@@ -55,7 +70,9 @@ __device__ __forceinline__ float readlane_f(int bits, int lane) {
 constexpr int kWavesPerBlock = 4;
 
 // grid.x = ceil(n_items / 4), grid.y = column tiles of 64*VEC floats
-template <int VEC, int U>
+// POLICY bits (cache hints, chosen by measurement): 1 = non-temporal (col,val) stream,
+// 2 = non-temporal result stores, 4 = non-temporal gathered rows
+template <int VEC, int U, int POLICY>
 __global__ __launch_bounds__(256) void k_spmm_gather(
     const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
     const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
@@ -90,9 +107,24 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     vec_t acc = V::zero();
     const float *xl = X + lc;
 
+    auto store_row = [&](float *dst, const vec_t &v) {
+        if (!active) return;
+        if constexpr ((POLICY & 2) != 0)
+            V::store_nt(dst, v);
+        else
+            *reinterpret_cast<vec_t *>(dst) = v;
+    };
+    auto load_cv = [&](int idx) -> int2 {
+        if constexpr ((POLICY & 1) != 0) {
+            const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long *>(cv + idx));
+            return make_int2(static_cast<int>(raw), static_cast<int>(raw >> 32));
+        } else {
+            return cv[idx];
+        }
+    };
     auto flush_row = [&]() {
         // row r is complete: write it, move to the next one
-        if (active) *reinterpret_cast<vec_t *>(Y + int64_t(r) * ldy + lc) = V::add(acc, bvec);
+        store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
         acc = V::zero();
         ++r;
         if (r - rp_base == 64) {
@@ -104,20 +136,28 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     };
 
     int2 cur = make_int2(0, 0);
-    if (it.nnz_begin + lane < nnz_end) cur = cv[it.nnz_begin + lane];
+    if (it.nnz_begin + lane < nnz_end) cur = load_cv(it.nnz_begin + lane);
     for (int base = it.nnz_begin; base < nnz_end; base += 64) {
         const int2 mine = cur;
         cur = make_int2(0, 0);  // col 0 / weight 0: a harmless row for the padded tail
-        if (base + 64 + lane < nnz_end) cur = cv[base + 64 + lane];
+        if (base + 64 + lane < nnz_end) cur = load_cv(base + 64 + lane);
         const int n = min(64, nnz_end - base);
         for (int j0 = 0; j0 < n; j0 += U) {
             vec_t x[U];
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int c = readlane_i(mine.x, j0 + u);
+                const int cf = readlane_i(mine.x, j0 + u);
+                const int c = cf & 0x7fffffff;          // sign bit = "cold column" (plan.hip)
                 v[u] = readlane_f(mine.y, j0 + u);
-                x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
+                if constexpr ((POLICY & 4) != 0) {
+                    x[u] = V::load_nt(xl + int64_t(c) * ldx);
+                } else {
+                    if (cf < 0)
+                        x[u] = V::load_nt(xl + int64_t(c) * ldx);
+                    else
+                        x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -137,7 +177,7 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     } else {
         // last row with entries, then any trailing empty rows of the block
         while (r < it.row_end) {
-            if (active) *reinterpret_cast<vec_t *>(Y + int64_t(r) * ldy + lc) = V::add(acc, bvec);
+            store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
             acc = V::zero();
             ++r;
         }
@@ -182,16 +222,43 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
     }
 }
 
+// Tuning knob for experiments (tools/sweep_spmm.py): TGCN_SPMM_VARIANT = "<U>:<POLICY>".
+int variant_from_env() {
+    static const int v = [] {
+        const char *s = std::getenv("TGCN_SPMM_VARIANT");
+        int u = 8, pol = 3;  // measured best on c4: 8 rows in flight, streams marked non-temporal
+        if (s) std::sscanf(s, "%d:%d", &u, &pol);
+        return u * 16 + (pol & 7);
+    }();
+    return v;
+}
+
 template <int VEC>
 int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
                int64_t ldy, float *carry, hipStream_t stream) {
-    constexpr int U = 8;
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
     const int64_t ldc = round_up4(F);
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-        k_spmm_gather<VEC, U><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx,
-                                                        F, bias, Y, ldy, carry, ldc);
+#define TGCN_LAUNCH(UU, PP)                                                                      \
+    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, \
+                                                         F, bias, Y, ldy, carry, ldc)
+        if constexpr (VEC == 4) {
+            switch (variant_from_env()) {
+                case 4 * 16 + 0: TGCN_LAUNCH(4, 0); break;
+                case 16 * 16 + 0: TGCN_LAUNCH(16, 0); break;
+                case 8 * 16 + 1: TGCN_LAUNCH(8, 1); break;
+                case 8 * 16 + 2: TGCN_LAUNCH(8, 2); break;
+                case 8 * 16 + 4: TGCN_LAUNCH(8, 4); break;
+                case 8 * 16 + 7: TGCN_LAUNCH(8, 7); break;
+                case 16 * 16 + 3: TGCN_LAUNCH(16, 3); break;
+                case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;
+                default: TGCN_LAUNCH(8, 3); break;
+            }
+        } else {
+            TGCN_LAUNCH(8, 0);
+        }
+#undef TGCN_LAUNCH
         TGCN_HIP_CHECK(hipGetLastError());
     }
     if (b.n_fix > 0) {
