@@ -94,28 +94,39 @@ def measured_traffic(config, n_gpus):
         return None
 
 
-def epoch_time_ms(g, F, n_classes, reps=3):
+def epoch_time_ms(g, F, n_classes, fused, reps=3):
     """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
-    bwd, Adam(amsgrad) step) + eval forward + metric transfer to the host."""
+    bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
+    fused=False: the reference's loop body verbatim (torch CrossEntropyLoss on mask-indexed rows,
+    torch.optim.Adam) around pytextgcn_amd.GCN;  fused=True: the same steps with
+    pytextgcn_amd.functional.masked_cross_entropy and pytextgcn_amd.optim.Adam."""
     import pytextgcn_amd as pkg
+    from pytextgcn_amd.functional import masked_cross_entropy
     N = g.y.numel()
     model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
-    opt = torch.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
+    Opt = pkg.optim.Adam if fused else torch.optim.Adam
+    opt = Opt(model.parameters(), lr=0.05, amsgrad=True)
     crit = torch.nn.CrossEntropyLoss(reduction="mean")
     times = []
     for rep in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model.train()
-        out = model(g)[g.train_mask]
-        loss = crit(out, g.y[g.train_mask])
+        if fused:
+            loss = masked_cross_entropy(model(g), g.y, g.train_mask)
+        else:
+            out = model(g)[g.train_mask]
+            loss = crit(out, g.y[g.train_mask])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         model.eval()
         with torch.no_grad():
             logits = model(g)
-            crit(logits[g.val_mask], g.y[g.val_mask])
+            if fused:
+                masked_cross_entropy(logits, g.y, g.val_mask)
+            else:
+                crit(logits[g.val_mask], g.y[g.val_mask])
             pred_val = logits[g.val_mask].argmax(1).cpu().numpy()
             pred_train = logits[g.train_mask].argmax(1).cpu().numpy()
         loss.item()
@@ -226,10 +237,11 @@ def main():
     launch_bytes = 0.5 * (bytes_fwd + bytes_bwd)
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
 
-    epoch_ms = None
+    epoch_ms = epoch_ms_fused = None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
-        epoch_ms = epoch_time_ms(g, F, C)
+        epoch_ms = epoch_time_ms(g, F, C, fused=False)
+        epoch_ms_fused = epoch_time_ms(g, F, C, fused=True)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -256,6 +268,7 @@ def main():
                          "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
                          "algorithmic_bytes_per_launch": launch_bytes},
             "epoch_ms": epoch_ms,
+            "epoch_ms_fused": epoch_ms_fused,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac)

@@ -132,6 +132,29 @@ size_t tgcn_colsum_workspace_bytes(int64_t n_rows, int F);
 int tgcn_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out, void *workspace,
                 size_t workspace_bytes, tgcn_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step helpers (the caller of the path: flat_amazon.py:82,89,99-106).
+ *
+ * tgcn_masked_ce -- `CrossEntropyLoss(reduction='mean')(logits[mask], target[mask])`
+ * (flat_amazon.py:82,101-102) and, when dlogits != NULL, its gradient w.r.t. the FULL logits matrix
+ * (rows outside the mask get zeros), in one pass.
+ *   logits [n_rows, n_classes] fp32 stride ld;  target int64 [n_rows];  mask uint8/bool [n_rows]
+ *   inv_count = 1 / (number of rows in the mask) -- a host value: masks are static, count them once
+ *   loss      device scalar (fp32);  dlogits [n_rows, n_classes] stride ldd or NULL
+ */
+size_t tgcn_masked_ce_workspace_bytes(void);
+int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                   const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                   float *dlogits, int64_t ldd, void *workspace, size_t workspace_bytes,
+                   tgcn_stream stream);
+
+/* tgcn_adam_step -- one `torch.optim.Adam(..., amsgrad=...)` update of a flat fp32 tensor
+ * (flat_amazon.py:89,106), torch's single-tensor formula op for op, fused into one pass.
+ * max_exp_avg_sq = NULL means amsgrad=False.  `step` is the 1-based step count AFTER increment. */
+int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, tgcn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,11 +4,11 @@ Mirrors the reference's public surface (textgcn/__init__.py:1-4 exports `Text2Gr
 and `models`): `models.GCN(in, out, n_hidden_gcn=..., dropout=...)(graph)` runs the two GCNConv
 layers as hand-written HIP kernels (libtgcn.so, include/tgcn.h) on an AMD Instinct MI355X.
 """
-from . import models
+from . import functional, models, optim
 from .conv import GCNConv
 from .data import Data
 from .models import GCN
 from .plan import GraphPlan, clear_plan_cache, colsum, plan_for
 
-__all__ = ["models", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
+__all__ = ["models", "functional", "optim", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
            "clear_plan_cache"]

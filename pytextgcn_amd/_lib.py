@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
@@ -37,6 +37,11 @@ SIGNATURES = {
     "tgcn_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "tgcn_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
+    "tgcn_masked_ce_workspace_bytes": (c_size_t, []),
+    "tgcn_masked_ce": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
+                               c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                               c_double, c_double, c_double, c_double, c_int64, c_void_p]),
 }
 
 _lib = None

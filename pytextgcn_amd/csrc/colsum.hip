@@ -50,13 +50,18 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     }
 }
 
-__global__ void k_colsum_final(const float *__restrict__ partial, int nb, int F,
-                               float *__restrict__ out) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
+// 4 waves x 64 columns per workgroup: wave w adds partial rows w, w+4, ...; LDS combine in wave order
+__global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int nb, int F,
+                                                      float *__restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[int64_t(b) * F + f];
-    out[f] = s;
+    if (f < F)
+        for (int b = wave; b < nb; b += 4) s += partial[int64_t(b) * F + f];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && f < F) out[f] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 }  // namespace
@@ -64,7 +69,7 @@ __global__ void k_colsum_final(const float *__restrict__ partial, int nb, int F,
 int colsum_blocks(int64_t n_rows) {
     int64_t nb = (n_rows + 255) / 256;
     if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
+    if (nb > 1024) nb = 1024;
     return static_cast<int>(nb);
 }
 
@@ -79,7 +84,7 @@ int launch_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out
         k_colsum_partial<1><<<grid, 256, 0, stream>>>(G, ldg, n_rows, F, partial);
     }
     TGCN_HIP_CHECK(hipGetLastError());
-    k_colsum_final<<<(F + 255) / 256, 256, 0, stream>>>(partial, n_blocks, F, out);
+    k_colsum_final<<<(F + 63) / 64, 256, 0, stream>>>(partial, n_blocks, F, out);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }

@@ -1,0 +1,221 @@
+// Training-step kernels around the GCN (row A6 of SURVEY.md 8(a): flat_amazon.py:82,89,99-106).
+//
+//   k_masked_ce    criterion(outputs[g.train_mask], g.y[g.train_mask]) with CrossEntropyLoss('mean')
+//                  (flat_amazon.py:82,101-102) and its gradient w.r.t. the full logits matrix, in one
+//                  pass over [N, C]: replaces boolean-mask indexing, log_softmax, nll_loss and their
+//                  three backward kernels.  HBM-bound: reads N*C*4 (+ 9 B/row), writes N*C*4.
+//   k_adam         torch.optim.Adam(..., amsgrad=True).step() (flat_amazon.py:89,106), one fused
+//                  elementwise pass: reads p, g, m, v, vmax and writes p, m, v, vmax (36 B/element)
+//                  instead of ~10 separate multi-tensor kernels.  HBM-bound.
+// Both are deterministic (fixed-order two-stage reductions, no atomics).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace tgcn {
+namespace {
+
+constexpr int kCeBlocks = 1024;
+
+// LPR lanes cooperate on one row; a wave handles 64/LPR rows at a time.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ logits, int64_t ld, int C,
+                                                   const int64_t *__restrict__ target,
+                                                   const uint8_t *__restrict__ mask, int64_t n_rows,
+                                                   float inv_count, float *__restrict__ dlogits,
+                                                   int64_t ldd, float *__restrict__ partial) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t rows_per_iter = int64_t(gridDim.x) * 4 * RPW;
+    float loss = 0.f;
+    for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * RPW; r0 < n_rows; r0 += rows_per_iter) {
+        const int64_t r = r0 + sub;
+        const bool valid = r < n_rows;
+        const bool on = valid && mask[r] != 0;
+        const float *row = logits + (valid ? r : 0) * ld;
+        float m = -INFINITY;
+        if (on)
+            for (int c = sl; c < C; c += LPR) m = fmaxf(m, row[c]);
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float s = 0.f;
+        if (on)
+            for (int c = sl; c < C; c += LPR) s += expf(row[c] - m);
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float lse = m + logf(s);
+        int64_t t = 0;
+        if (on) {
+            t = target[r];
+            if (sl == 0) loss += lse - row[t];
+        }
+        if (dlogits != nullptr && valid) {
+            float *drow = dlogits + r * ldd;
+            for (int c = sl; c < C; c += LPR)
+                drow[c] = on ? (expf(row[c] - lse) - (c == t ? 1.f : 0.f)) * inv_count : 0.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
+    if (lane == 0) red[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_ce_final(const float *__restrict__ partial, int n, float inv_count,
+                           float *__restrict__ loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_count;
+}
+
+// at::lerp: the branch keeps the result monotone in the weight
+__device__ __forceinline__ float lerp_torch(float a, float b, float w) {
+    return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w);
+}
+
+// torch/optim/adam.py (_single_tensor_adam), op for op:
+//   g += wd * p;  m.lerp_(g, 1-b1);  v = b2*v + (1-b2)*g*g;  vmax = max(vmax, v)   [amsgrad]
+//   denom = sqrt(vmax or v) / sqrt(1 - b2^t) + eps;  p -= (lr / (1 - b1^t)) * m / denom
+template <bool AMSGRAD>
+__global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
+                                              float *__restrict__ m, float *__restrict__ v,
+                                              float *__restrict__ vmax, int64_t n, float w1 /* 1-b1 */,
+                                              float b2, float w2 /* 1-b2 */, float eps, float wd,
+                                              float step_size, float inv_bc2_sqrt) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x * 4;
+    for (int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 pp = *reinterpret_cast<float4 *>(p + i);
+            const float4 gg = *reinterpret_cast<const float4 *>(g + i);
+            float4 mm = *reinterpret_cast<float4 *>(m + i);
+            float4 vv = *reinterpret_cast<float4 *>(v + i);
+            float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AMSGRAD) xx = *reinterpret_cast<float4 *>(vmax + i);
+            float *P = &pp.x, *M = &mm.x, *V = &vv.x, *X = &xx.x;
+            const float *G = &gg.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gr = G[k] + wd * P[k];
+                M[k] = lerp_torch(M[k], gr, w1);
+                V[k] = V[k] * b2 + w2 * gr * gr;
+                float d = V[k];
+                if (AMSGRAD) {
+                    X[k] = fmaxf(X[k], V[k]);
+                    d = X[k];
+                }
+                const float denom = sqrtf(d) * inv_bc2_sqrt + eps;
+                P[k] = P[k] - step_size * (M[k] / denom);
+            }
+            *reinterpret_cast<float4 *>(p + i) = pp;
+            *reinterpret_cast<float4 *>(m + i) = mm;
+            *reinterpret_cast<float4 *>(v + i) = vv;
+            if (AMSGRAD) *reinterpret_cast<float4 *>(vmax + i) = xx;
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                const float gr = g[j] + wd * p[j];
+                const float mj = lerp_torch(m[j], gr, w1);
+                const float vj = v[j] * b2 + w2 * gr * gr;
+                float d = vj;
+                if (AMSGRAD) {
+                    d = fmaxf(vmax[j], vj);
+                    vmax[j] = d;
+                }
+                m[j] = mj;
+                v[j] = vj;
+                p[j] = p[j] - step_size * (mj / (sqrtf(d) * inv_bc2_sqrt + eps));
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace tgcn
+
+extern "C" {
+
+size_t tgcn_masked_ce_workspace_bytes(void) { return sizeof(float) * tgcn::kCeBlocks; }
+
+int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                   const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                   float *dlogits, int64_t ldd, void *workspace, size_t workspace_bytes,
+                   tgcn_stream stream) {
+    using namespace tgcn;
+    if (!logits || !target || !mask || !loss || n_rows < 0 || n_classes <= 0 || ld < n_classes ||
+        (dlogits && ldd < n_classes)) {
+        set_error("tgcn_masked_ce: bad argument (n_rows=%lld C=%d ld=%lld)", (long long)n_rows,
+                  n_classes, (long long)ld);
+        return TGCN_E_INVALID;
+    }
+    if (!workspace || workspace_bytes < tgcn_masked_ce_workspace_bytes()) {
+        set_error("tgcn_masked_ce: workspace of %zu bytes given, %zu needed", workspace_bytes,
+                  tgcn_masked_ce_workspace_bytes());
+        return TGCN_E_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *partial = static_cast<float *>(workspace);
+    int64_t rows_per_block = 4 * (n_classes <= 16 ? 16 : n_classes <= 32 ? 8 : n_classes <= 64 ? 4 : n_classes <= 128 ? 2 : 1);
+    int grid = static_cast<int>(std::min<int64_t>(kCeBlocks, std::max<int64_t>(1, (n_rows + rows_per_block - 1) / rows_per_block)));
+    if (n_classes <= 16)
+        k_masked_ce<4><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+    else if (n_classes <= 32)
+        k_masked_ce<8><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+    else if (n_classes <= 64)
+        k_masked_ce<16><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+    else if (n_classes <= 128)
+        k_masked_ce<32><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+    else
+        k_masked_ce<64><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+    TGCN_HIP_CHECK(hipGetLastError());
+    k_ce_final<<<1, 256, 0, s>>>(partial, grid, inv_count, loss);
+    TGCN_HIP_CHECK(hipGetLastError());
+    return TGCN_OK;
+}
+
+int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, tgcn_stream stream) {
+    using namespace tgcn;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) {
+        set_error("tgcn_adam_step: bad argument (n=%lld step=%lld)", (long long)n, (long long)step);
+        return TGCN_E_INVALID;
+    }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                        reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
+                        reinterpret_cast<uintptr_t>(max_exp_avg_sq);
+    if (a % 16 != 0) {
+        set_error("tgcn_adam_step: buffers must be 16-byte aligned");
+        return TGCN_E_INVALID;
+    }
+    if (n == 0) return TGCN_OK;
+    // hyper-parameters are Python floats (doubles) in torch: derive every constant in double and
+    // round once, as torch does when it hands `1 - beta2`, `lr / bias_correction1`, ... to its kernels
+    const double bc1 = 1.0 - std::pow(beta1, static_cast<double>(step));
+    const double bc2 = 1.0 - std::pow(beta2, static_cast<double>(step));
+    const float step_size = static_cast<float>(lr / bc1);
+    const float w1 = static_cast<float>(1.0 - beta1), w2 = static_cast<float>(1.0 - beta2);
+    const float b2f = static_cast<float>(beta2), epsf = static_cast<float>(eps), wdf = static_cast<float>(weight_decay);
+    const float inv_bc2_sqrt = static_cast<float>(1.0 / std::sqrt(bc2));
+    const int grid = static_cast<int>(std::min<int64_t>(8192, (n / 4 + 255) / 256 + 1));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (max_exp_avg_sq)
+        k_adam<true><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, w1, b2f, w2,
+                                          epsf, wdf, step_size, inv_bc2_sqrt);
+    else
+        k_adam<false><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, nullptr, n, w1, b2f, w2, epsf,
+                                           wdf, step_size, inv_bc2_sqrt);
+    TGCN_HIP_CHECK(hipGetLastError());
+    return TGCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Fused training-step operators around the GCN (the caller of the path, flat_amazon.py:82,99-106).
+
+`masked_cross_entropy(logits, target, mask)` equals
+`CrossEntropyLoss(reduction='mean')(logits[mask], target[mask])` -- what the reference computes at
+flat_amazon.py:101-102 (train) and :110 (validation) -- but runs as ONE HIP kernel over the full
+[N, C] logits (libtgcn.so `tgcn_masked_ce`) that also produces the gradient, instead of boolean-mask
+indexing + log_softmax + nll_loss and their backward kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .plan import _require_cuda, _stream_ptr
+
+_COUNT_CACHE: dict = {}
+
+
+def _mask_count(mask: Tensor) -> int:
+    """Rows selected by a (static) mask; one device sync per distinct mask version."""
+    key = (mask.data_ptr(), mask._version, mask.numel(), mask.device)
+    hit = _COUNT_CACHE.get(key)
+    if hit is None:
+        if len(_COUNT_CACHE) > 64:
+            _COUNT_CACHE.clear()
+        hit = _COUNT_CACHE[key] = int(mask.sum().item())
+    return hit
+
+
+def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool):
+    lib = _lib.load()
+    _require_cuda(logits, "logits")
+    if logits.dtype != torch.float32 or logits.dim() != 2:
+        raise TypeError("logits must be a 2-D float32 tensor")
+    n, C = logits.shape
+    if target.shape != (n,) or mask.shape != (n,):
+        raise ValueError("target and mask must have one entry per logits row")
+    if mask.dtype != torch.bool:
+        raise TypeError("mask must be a bool tensor")
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    target = target.long().contiguous()
+    mask = mask.contiguous()
+    count = _mask_count(mask)
+    inv = 1.0 / count if count else float("nan")          # torch: mean over an empty selection = nan
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device) if want_grad else None
+    ws_bytes = lib.tgcn_masked_ce_workspace_bytes()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
+    _lib.check(lib.tgcn_masked_ce(
+        logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(), mask.data_ptr(),
+        ctypes.c_float(inv), loss.data_ptr(),
+        dlogits.data_ptr() if dlogits is not None else None, C,
+        ws.data_ptr(), ws_bytes, _stream_ptr(logits.device)))
+    return loss, dlogits
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor):
+        loss, dlogits = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0])
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits.mul_(grad_out), None, None          # dlogits is ours: scale in place
+
+
+def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor) -> Tensor:
+    if logits.requires_grad and torch.is_grad_enabled():
+        return _MaskedCE.apply(logits, target, mask)
+    return _launch(logits, target, mask, False)[0]

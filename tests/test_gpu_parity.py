@@ -351,3 +351,78 @@ def test_config_c4_row_block_against_reference_formulation(cuda):
     ref = csr_oracle.csr_spmm(rp[:R + 1].cpu().long(), col[:nn_].cpu(), val[:nn_].cpu(), x.cpu(),
                               acc64=True)
     assert rel_err(out, ref) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# training-step helpers (row A6): fused masked cross-entropy and Adam(amsgrad)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,C", [(1, 2), (37, 3), (1000, 16), (5000, 64), (777, 219), (300, 300)])
+def test_masked_cross_entropy_matches_torch(cuda, n, C):
+    from pytextgcn_amd.functional import masked_cross_entropy
+    gen = torch.Generator().manual_seed(n + C)
+    logits = (torch.randn(n, C, generator=gen) * 3).requires_grad_()
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.6
+    mask[0] = True
+    ref = torch.nn.CrossEntropyLoss(reduction="mean")(logits[mask], y[mask])   # flat_amazon.py:82,101-102
+    ref.backward()
+    lg = logits.detach().to(cuda).requires_grad_()
+    loss = masked_cross_entropy(lg, y.to(cuda), mask.to(cuda))
+    (loss * 1.0).backward()
+    assert abs(loss.item() - ref.item()) < TOL * abs(ref.item()) + 1e-7
+    assert rel_err(lg.grad, logits.grad) < TOL
+    with torch.no_grad():
+        assert abs(masked_cross_entropy(lg, y.to(cuda), mask.to(cuda)).item() - ref.item()) < TOL * abs(ref.item()) + 1e-7
+    big = torch.randn(n, C + 5, generator=gen).to(cuda)                      # strided logits
+    a = masked_cross_entropy(big[:, 2:2 + C], y.to(cuda), mask.to(cuda))
+    b = torch.nn.functional.cross_entropy(big[:, 2:2 + C].cpu()[mask], y[mask])
+    assert abs(a.item() - b.item()) < TOL * abs(b.item()) + 1e-7
+
+
+@pytest.mark.parametrize("amsgrad,wd", [(True, 0.0), (False, 0.0), (True, 0.01)])
+def test_fused_adam_matches_torch(cuda, amsgrad, wd):
+    from pytextgcn_amd.optim import Adam
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(1000, 200), (200, 64), (64,), (3,)]
+    ref_p = [torch.randn(s, generator=gen).requires_grad_() for s in shapes]
+    my_p = [p.detach().clone().to(cuda).requires_grad_() for p in ref_p]
+    o_r = torch.optim.Adam(ref_p, lr=0.05, amsgrad=amsgrad, weight_decay=wd)     # flat_amazon.py:89
+    o_m = Adam(my_p, lr=0.05, amsgrad=amsgrad, weight_decay=wd)
+    for step in range(6):
+        for pr, pm in zip(ref_p, my_p):
+            g = torch.randn(pr.shape, generator=gen) * (0.1 if step % 2 else 1.0)
+            pr.grad, pm.grad = g, g.to(cuda)
+        o_r.step(), o_m.step()
+        for pr, pm in zip(ref_p, my_p):
+            assert rel_err(pm, pr) < TOL, (step, pr.shape)
+    st = o_m.state[my_p[0]]
+    assert st["step"] == 6 and ("max_exp_avg_sq" in st) == amsgrad
+    assert rel_err(st["exp_avg_sq"], o_r.state[ref_p[0]]["exp_avg_sq"]) < TOL
+
+
+def test_fused_training_loop_tracks_the_oracle(cuda):
+    """The epoch of flat_amazon.py:99-109 with the fused loss and optimizer vs the oracle with torch's."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.optim import Adam
+    N, C = 1500, 6
+    g = synth.word_doc_graph(N, 20000, seed=16, n_classes=C)
+    torch.manual_seed(4)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=32, dropout=0.0)
+    mine = pkg.GCN(N, C, n_hidden_gcn=32, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    o_r = torch.optim.Adam(ref.parameters(), lr=0.05, amsgrad=True)
+    o_m = Adam(mine.parameters(), lr=0.05, amsgrad=True)
+    for step in range(4):
+        l_r, z_r = O.train_step(ref, g, o_r)
+        mine.train()
+        loss = masked_cross_entropy(mine(gd), gd.y, gd.train_mask)
+        o_m.zero_grad(set_to_none=True)
+        loss.backward()
+        o_m.step()
+        mine.eval()
+        with torch.no_grad():
+            z_m = mine(gd)
+        assert abs(loss.item() - l_r.item()) < 1e-4 * abs(l_r.item()), step
+        assert rel_err(z_m, z_r) < 1e-3, step
