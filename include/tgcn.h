@@ -155,6 +155,26 @@ int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, tgcn_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Word-word PMI edges (graph construction).  Replaces the reference's Cython
+ * entry point `compute_word_word_edges(X, n_vocab, n_documents, seq_len, window_size, n_jobs, verbose)`
+ * (textgcn/lib/clib/graphbuilder.pyx:23-25, called at text2graph.py:156-160) and its test hook
+ * `sliding_window_tester` (:263-275).  Results are bit-identical to the reference: same uint32
+ * counts, same edge order ((i,j),(j,i) interleaved, upper triangle row-major), same float32 PMI.
+ *   X   int32 [n_docs, seq_len] row-major DEVICE pointer, tokens in [0, n_vocab), -1 = padding
+ * The handle owns its outputs (the reference leaks its malloc'd arrays, :65-66); export copies
+ * them to host or device buffers (hipMemcpyDefault) and synchronises the stream.
+ */
+typedef struct tgcn_wwedges tgcn_wwedges;
+enum { TGCN_WW_N_EDGES = 0, TGCN_WW_N_WINDOWS = 1, TGCN_WW_N_COUNTS = 2 /* n_vocab*(n_vocab+1)/2 */ };
+int tgcn_wwedges_create(const int32_t *X, int64_t n_docs, int64_t seq_len, int64_t n_vocab,
+                        int64_t window, int device, tgcn_stream stream, tgcn_wwedges **out);
+int tgcn_wwedges_query(const tgcn_wwedges *we, int what, int64_t *out);
+int tgcn_wwedges_export(const tgcn_wwedges *we, int32_t *coo /* [n_edges][2] */,
+                        float *weights /* [n_edges] */, uint32_t *cij /* packed triangle or NULL */,
+                        tgcn_stream stream);
+int tgcn_wwedges_destroy(tgcn_wwedges *we);
+
 #ifdef __cplusplus
 }
 #endif

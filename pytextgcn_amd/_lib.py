@@ -40,6 +40,11 @@ SIGNATURES = {
     "tgcn_masked_ce_workspace_bytes": (c_size_t, []),
     "tgcn_masked_ce": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
                                c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_wwedges_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p,
+                                    POINTER(c_void_p)]),
+    "tgcn_wwedges_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
+    "tgcn_wwedges_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tgcn_wwedges_destroy": (c_int, [c_void_p]),
     "tgcn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                c_double, c_double, c_double, c_double, c_int64, c_void_p]),
 }

@@ -1,0 +1,86 @@
+"""Word-word PMI edges: drop-in for the reference's Cython module
+`textgcn.lib.clib.graphbuilder` (exported through textgcn/lib/__init__.py:1-4), running on the GPU
+through libtgcn.so (`tgcn_wwedges_*`, pytextgcn_amd/csrc/graphbuilder.hip).
+
+Same call signatures and return conventions as graphbuilder.pyx:23-68 and :263-275: host numpy
+arrays in, host numpy arrays out (`coo` int32 [n_edges, 2], `weights` float32 [n_edges]), so that
+`Text2GraphTransformer` (text2graph.py:156-160) and the reference's tests (test_cfunc.py:81-111)
+read the same.  `n_jobs` is accepted and unused, as in the reference (graphbuilder.pyx:36).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .plan import _stream_ptr
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pytextgcn_amd.graphbuilder runs on an AMD GPU through libtgcn.so "
+                           "(there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _run(X, n_vocab: int, n_documents: int, seq_len: int, window_size: int):
+    lib = _lib.load()
+    dev = _device()
+    Xt = torch.as_tensor(np.ascontiguousarray(X, dtype=np.int32) if not torch.is_tensor(X) else X)
+    if Xt.dtype != torch.int32:
+        Xt = Xt.to(torch.int32)
+    if tuple(Xt.shape) != (n_documents, seq_len):
+        raise ValueError(f"X has shape {tuple(Xt.shape)}, expected ({n_documents}, {seq_len})")
+    if Xt.numel() and (int(Xt.max()) >= n_vocab or int(Xt.min()) < -1):
+        raise IndexError("tokens must lie in [0, n_vocab) or be the padding value -1")
+    Xd = Xt.to(dev).contiguous()
+    h = ctypes.c_void_p()
+    _lib.check(lib.tgcn_wwedges_create(Xd.data_ptr() if Xd.numel() else None, n_documents, seq_len,
+                                       n_vocab, window_size, dev.index, _stream_ptr(dev),
+                                       ctypes.byref(h)))
+    return lib, h, dev
+
+
+def _query(lib, h, what: int) -> int:
+    out = ctypes.c_int64()
+    _lib.check(lib.tgcn_wwedges_query(h, what, ctypes.byref(out)))
+    return int(out.value)
+
+
+def compute_word_word_edges(X, n_vocab: int, n_documents: int, seq_len: int, window_size: int = 20,
+                            n_jobs: int = 1, verbose: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    lib, h, dev = _run(X, n_vocab, n_documents, seq_len, window_size)
+    try:
+        n = _query(lib, h, 0)
+        coo = np.empty((n, 2), dtype=np.int32)
+        w = np.empty(n, dtype=np.float32)
+        _lib.check(lib.tgcn_wwedges_export(h, coo.ctypes.data if n else None,
+                                           w.ctypes.data if n else None, None, _stream_ptr(dev)))
+        if verbose > 1:
+            print(f"Number of word-word-edges: {n}")
+        return coo, w
+    finally:
+        lib.tgcn_wwedges_destroy(h)
+
+
+def sliding_window_tester(X, n_vocab: int, n_documents: int, seq_len: int, window_size: int = 20,
+                          n_jobs: int = 1) -> np.ndarray:
+    """Packed upper triangle (incl. diagonal) of the co-occurrence counts, uint32."""
+    lib, h, dev = _run(X, n_vocab, n_documents, seq_len, window_size)
+    try:
+        c = np.empty(_query(lib, h, 2), dtype=np.uint32)
+        _lib.check(lib.tgcn_wwedges_export(h, None, None, c.ctypes.data, _stream_ptr(dev)))
+        return c
+    finally:
+        lib.tgcn_wwedges_destroy(h)
+
+
+def n_windows(X, n_vocab: int, n_documents: int, seq_len: int, window_size: int = 20) -> int:
+    lib, h, _ = _run(X, n_vocab, n_documents, seq_len, window_size)
+    try:
+        return _query(lib, h, 1)
+    finally:
+        lib.tgcn_wwedges_destroy(h)

@@ -69,9 +69,9 @@ def main():
     conv_case("random53_noloops_unweighted", ei, None, n, 5, 7, seed=12, add_self_loops=False)
 
     # (3) tiny TextGCN-shaped graph: V = 6 words from the reference's Cython golden input
-    #     (test_cfunc.py:83-87 -> word-word edges of SURVEY.md section 4) + 2 documents, through
+    #     (test_cfunc.py:105-108 -> word-word edges of SURVEY.md section 4) + 2 documents, through
     #     the 2-layer GCN with dropout = 0: logits, loss, all gradients, and 3 Adam(amsgrad) steps.
-    X = np.array([[0, 1, 2, 0, 0, 0, 0, 5], [3, 4, 3, 4, 3, 4, 3, 4]], dtype=np.int32)
+    X = np.array([[0, 1, 2, 3, 4, -1, -1, -1], [5, 3, 4, 1, 2, 0, 5, 1]], dtype=np.int32)   # test_cfunc.py:105-108
     ww = np.array([[0, 1, 0, 2, 0, 5, 3, 4], [1, 0, 2, 0, 5, 0, 4, 3]], dtype=np.int64)
     ww_w = np.array([0.11778303, 0.11778303, 0.11778303, 0.11778303, 0.4054651, 0.4054651,
                      0.52324814, 0.52324814], dtype=np.float32)
@@ -79,7 +79,8 @@ def main():
     occ = np.zeros((D, V))
     for d in range(D):
         for t in X[d]:
-            occ[d, t] += 1
+            if t >= 0:
+                occ[d, t] += 1
     # sklearn TfidfTransformer defaults: smooth idf, l2 norm
     df = (occ > 0).sum(0)
     idf = np.log((1 + D) / (1 + df)) + 1
