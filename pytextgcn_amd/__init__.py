@@ -9,6 +9,7 @@ from .conv import GCNConv
 from .data import Data
 from .models import GCN
 from .plan import GraphPlan, clear_plan_cache, colsum, plan_for
+from .text2graph import Text2GraphTransformer
 
-__all__ = ["models", "functional", "optim", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
+__all__ = ["Text2GraphTransformer", "models", "functional", "optim", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
            "clear_plan_cache"]
