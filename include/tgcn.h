@@ -156,6 +156,23 @@ int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    double weight_decay, int64_t step, tgcn_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tall-skinny fp32 GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32): the dense
+ * `torch.matmul(x, self.weight)` of PyG-1.6.3 GCNConv.forward (reference call site models.py:20,
+ * layers built at models.py:13,15) and its autograd.  N = number of nodes; k, n = layer widths <= 256
+ * with k_pad * n_pad * 4 bytes <= 160 KB (the small operand lives in LDS).
+ *   tgcn_gemm_nn   C[N,n] = A[N,k] @ B[k,n]        (XW  = H @ W)        A: lda % 4 == 0, 16-B aligned
+ *   tgcn_gemm_nt   C[N,n] = A[N,k] @ B[n,k]^T      (dH  = dXW @ W^T)    A: lda % 4 == 0, 16-B aligned
+ *   tgcn_gemm_tn   C[k,n] = A[N,k]^T @ G[N,n]      (dW  = H^T @ dXW)    n <= 128; deterministic
+ */
+int tgcn_gemm_nn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 int64_t N, int k, int n, tgcn_stream stream);
+int tgcn_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 int64_t N, int k, int n, tgcn_stream stream);
+size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n);
+int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                 int64_t N, int k, int n, void *workspace, size_t workspace_bytes, tgcn_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Word-word PMI edges (graph construction).  Replaces the reference's Cython
  * entry point `compute_word_word_edges(X, n_vocab, n_documents, seq_len, window_size, n_jobs, verbose)`
  * (textgcn/lib/clib/graphbuilder.pyx:23-25, called at text2graph.py:156-160) and its test hook

@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+from . import dense
 from .plan import GraphPlan, colsum, plan_for
 
 
@@ -122,7 +123,7 @@ class GCNConv(nn.Module):
             # layer 1 of TextGCN: one-hot features, so X @ W1 is W1 (and dW1 = dXW, no GEMM)
             xw = self.weight if is_sparse_identity(x) else torch.sparse.mm(x, self.weight)
         else:
-            xw = torch.matmul(x, self.weight)
+            xw = dense.xw(x, self.weight)     # fp32 MFMA kernels for tall-skinny shapes
         return propagate(plan, xw, self.bias)
 
     def __repr__(self) -> str:

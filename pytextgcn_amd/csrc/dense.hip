@@ -1,0 +1,395 @@
+// Tall-skinny fp32 GEMMs of the GCN layers on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit an fma chain; gfx950 has no xf32/TF32 path, and the 1e-5 parity bar forbids bf16).
+//
+// They replace `torch.matmul(x, self.weight)` of PyG-1.6.3 GCNConv.forward (k5 of SURVEY.md 2a;
+// reference call site textgcn/lib/models.py:20) for the DENSE layers and its autograd (b1-b4):
+//     tgcn_gemm_nn   C[N, n]  = A[N, k] @ B[k, n]          XW2  = H1d @ W2      (k = h, n = C)
+//     tgcn_gemm_nt   C[N, n]  = A[N, k] @ B[n, k]^T        dH1d = dXW2 @ W2^T   (k = C, n = h)
+//     tgcn_gemm_tn   C[k, n]  = A[N, k]^T @ G[N, n]        dW2  = H1d^T @ dXW2  (reduction over N)
+// N is the node count (millions), k and n are layer widths (<= 256): every operand row is read
+// exactly once, so the kernels are co-bound by HBM (N*(k+n)*4 bytes) and by the fp32 MFMA rate
+// (2*N*k*n flop at 157 TF/s peak); at N = 2 M, k = 200, n = 64 both limits are ~0.35 ms.
+//
+// Fragment maps (cdna_hip_programming.md section 3): for 32x32x2, lane l feeds A[i = l&31][k = l>>5]
+// and B[k = l>>5][j = l&31]; the accumulator register r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)]
+// [l&31].  The sum over k is order-independent, which the nn/nt kernels use to load 4 consecutive k
+// of one row with ONE float4 per lane (lanes 0-31 take k = 8q..8q+3, lanes 32-63 k = 8q+4..8q+7) and
+// spend it over 4 MFMA steps; the matching rows of the small operand sit in LDS.
+#include <algorithm>
+
+#include "common.h"
+
+namespace tgcn {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxSmall = 256;  // k, n <= 256
+
+// ---------------------------------------------------------------------------------------------
+// C[N, n] = A[N, k] @ Bs, where Bs[kk][j] is the small operand staged in LDS as [kpad][npad].
+// One wave per 32 rows, NT tiles of 32 columns each (npad = 32*NT).  TRANS_B selects how the small
+// operand is read from memory: B[k][n] (nn) or B[n][k] (nt).
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool TRANS_B, bool K8>
+__global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
+                                                   const float *__restrict__ B, int64_t ldb,
+                                                   float *__restrict__ C, int64_t ldc, int64_t N,
+                                                   int k, int n) {
+    extern __shared__ float lds[];  // [kpad][npad]
+    constexpr int npad = 32 * NT;
+    const int kpad = (k + 7) & ~7;
+    // stage the small operand, zero padded
+    for (int idx = threadIdx.x; idx < kpad * npad; idx += blockDim.x) {
+        const int kk = idx / npad, j = idx % npad;
+        float v = 0.f;
+        if (kk < k && j < n) v = TRANS_B ? B[int64_t(j) * ldb + kk] : B[int64_t(kk) * ldb + j];
+        lds[idx] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int64_t n_blocks = (N + 31) / 32;
+    const int nq = kpad / 8;
+    for (int64_t blk = int64_t(blockIdx.x) * 4 + wave; blk < n_blocks; blk += int64_t(gridDim.x) * 4) {
+        const int64_t row = blk * 32 + r;
+        // rows past the end shadow the last row: loads stay in bounds, their results are not stored
+        const float *arow = A + std::min(row, N - 1) * lda + 4 * half;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        auto load_a = [&](int q) -> float4 {
+            if (q >= nq) return make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (K8) {
+                return *reinterpret_cast<const float4 *>(arow + 8 * q);
+            } else {
+                const int k0 = 8 * q + 4 * half;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + 3 < k) {
+                    v = *reinterpret_cast<const float4 *>(arow + 8 * q);
+                } else {
+                    if (k0 < k) v.x = arow[8 * q];
+                    if (k0 + 1 < k) v.y = arow[8 * q + 1];
+                    if (k0 + 2 < k) v.z = arow[8 * q + 2];
+                }
+                return v;
+            }
+        };
+        // B fragments of step group q: rows 8q + 4 half + s, columns r + 32 t; software pipeline:
+        // three A pieces in flight, next group's B fragments read from LDS under the current MFMAs.
+        // (A static 4-deep ring with the loop unrolled by 4 measured slower: 0.81 vs 0.73 ms.)
+        const float *bbase = lds + (4 * half) * npad + r;
+        float bcur[4][NT], bnxt[4][NT];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bcur[s4][t] = bbase[s4 * npad + 32 * t];
+        float4 a0 = load_a(0), a1 = load_a(1), a2 = load_a(2);
+        for (int q = 0; q < nq; ++q) {
+            const float4 a3 = load_a(q + 3);
+            if (q + 1 < nq) {
+                const float *bq = bbase + (8 * (q + 1)) * npad;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bnxt[s4][t] = bq[s4 * npad + 32 * t];
+            }
+            const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bcur[s4][t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bcur[s4][t] = bnxt[s4][t];
+            a0 = a1;
+            a1 = a2;
+            a2 = a3;
+        }
+        // C[(i&3) + 8*(i>>2) + 4*half][32 t + r]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = 32 * t + r;
+            if (col < n) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    if (orow < N) C[orow * ldc + col] = acc[t][i];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// partial[b][kpad][npad] = sum over this workgroup's rows of A[r, :]^T G[r, :]
+// Both operands are read straight from global memory in fragment order: for one MFMA step (2 rows)
+// lanes 0-31 / 32-63 read 32 consecutive floats of row 2s / 2s+1 (two coalesced 128-byte segments).
+// 4 waves per workgroup; wave w owns the M-tiles {w, w+4} (of kpad/32 <= 8) x all NT column tiles.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restrict__ A, int64_t lda,
+                                                            const float *__restrict__ G, int64_t ldg,
+                                                            int64_t N, int k, int n, int64_t rows_per_wg,
+                                                            float *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int mt = (k + 31) / 32;  // M tiles
+    constexpr int npad = 32 * NT;
+    const int mpad = 32 * mt;
+    const int64_t r_begin = int64_t(blockIdx.x) * rows_per_wg;
+    const int64_t r_end = std::min(N, r_begin + rows_per_wg);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+    // Columns past k (of A) or n (of G) are clamped to a valid address and NOT zeroed: they only
+    // feed rows >= k / columns >= n of the padded result tile, which nobody reads.  That keeps the
+    // main loop free of per-lane conditions (a conditional load makes hipcc wait vmcnt(0) per load).
+    const int m0 = wave, m1 = wave + 4;
+    const float *pa0 = A + r_begin * lda + half * lda + std::min(32 * m0 + c, k - 1);
+    const float *pa1 = A + r_begin * lda + half * lda + std::min(32 * m1 + c, k - 1);
+    const float *pg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pg[t] = G + r_begin * ldg + half * ldg + std::min(32 * t + c, n - 1);
+    constexpr int UR = 4;  // row pairs per stage; two stages in flight (static double buffer)
+    const int64_t n_rows = r_end > r_begin ? r_end - r_begin : 0;
+    const int64_t n_full = n_rows / (2 * UR);
+    float a0[2][UR], a1[2][UR], g[2][UR][NT];
+    auto load_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            a0[buf][u] = pa0[int64_t(2 * u) * lda];
+            a1[buf][u] = pa1[int64_t(2 * u) * lda];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) g[buf][u][t] = pg[t][int64_t(2 * u) * ldg];
+        }
+        pa0 += 2 * UR * lda;
+        pa1 += 2 * UR * lda;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pg[t] += 2 * UR * ldg;
+    };
+    auto mfma_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[buf][u], g[buf][u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[buf][u], g[buf][u][t], acc[1][t], 0, 0, 0);
+            }
+    };
+    if (n_full > 0) load_stage(0);
+    for (int64_t it = 0; it < n_full; it += 2) {
+        if (it + 1 < n_full) load_stage(1);
+        mfma_stage(0);
+        if (it + 1 < n_full) {
+            if (it + 2 < n_full) load_stage(0);
+            mfma_stage(1);
+        }
+    }
+    // ragged tail of the row range: rows past the end contribute zeros
+    for (int64_t r = n_full * 2 * UR; r < n_rows; r += 2) {
+        const bool ok = r + half < n_rows;
+        const int64_t back = ok ? 0 : 1;      // the odd last row: re-read the previous one, scaled by 0
+        const float s = ok ? 1.f : 0.f;
+        const float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float y = pg[t][-back * ldg] * s;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, acc[1][t], 0, 0, 0);
+        }
+        pa0 += 2 * lda;
+        pa1 += 2 * lda;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pg[t] += 2 * ldg;
+    }
+    float *out = partial + int64_t(blockIdx.x) * mpad * npad;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mtile = m == 0 ? m0 : m1;
+        if (mtile >= mt) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int orow = 32 * mtile + (i & 3) + 8 * (i >> 2) + 4 * half;
+                out[orow * npad + 32 * t + c] = acc[m][t][i];
+            }
+    }
+}
+
+// C[kk][j] = sum_b partial[b][kk][j], in block order (deterministic); one thread per element,
+// 4-way split over b combined through LDS to shorten the serial chain.
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict__ partial, int nb,
+                                                        int mpad, int npad, int k, int n,
+                                                        float *__restrict__ C, int64_t ldc) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;  // element of the [k][n] result
+    const int kk = e / n, j = e % n;
+    float s = 0.f;
+    if (e < k * n) {
+        const float *p = partial + int64_t(kk) * npad + j;
+        const int64_t stride = int64_t(mpad) * npad;
+        int b = wave;
+        for (; b + 28 < nb; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(b + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nb; b += 4) s += p[b * stride];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && e < k * n) C[int64_t(kk) * ldc + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+int tn_blocks(int64_t N) {
+    // 2 workgroups per CU (launch bounds), one resident round: 512 on MI355X
+    int64_t nb = (N + 1023) / 1024;
+    return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(nb, 512)));
+}
+
+template <bool TRANS_B>
+int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                int64_t N, int k, int n, hipStream_t s) {
+    const int nt = (n + 31) / 32;
+    const int kpad = (k + 7) & ~7;
+    const size_t lds_bytes = sizeof(float) * static_cast<size_t>(kpad) * (32 * nt);
+    if (lds_bytes > 160 * 1024) {
+        set_error("tgcn_gemm: the small operand (%d x %d) does not fit the 160 KB LDS", k, n);
+        return TGCN_E_INVALID;
+    }
+    const int64_t n_blocks = (N + 31) / 32;
+    // persistent workgroups: exactly one resident set (a second, partial round of workgroups would
+    // leave most CUs idle at the end)
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+    }
+#define TGCN_TALL_K(NT, K8)                                                                       \
+    do {                                                                                          \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8>);           \
+        TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                           static_cast<int>(lds_bytes)));                         \
+        int per_cu = 1;                                                                           \
+        TGCN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes)); \
+        per_cu = std::max(1, std::min(per_cu, 4));                                                \
+        const int grid = static_cast<int>(                                                        \
+            std::max<int64_t>(1, std::min<int64_t>((n_blocks + 3) / 4, int64_t(n_cu) * per_cu))); \
+        k_gemm_tall<NT, TRANS_B, K8><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n); \
+    } while (0)
+#define TGCN_TALL(NT)                                                                             \
+    do {                                                                                          \
+        if (k % 8 == 0)                                                                           \
+            TGCN_TALL_K(NT, true);                                                                \
+        else                                                                                      \
+            TGCN_TALL_K(NT, false);                                                               \
+    } while (0)
+    switch (nt) {
+        case 1: TGCN_TALL(1); break;
+        case 2: TGCN_TALL(2); break;
+        case 3: TGCN_TALL(3); break;
+        case 4: TGCN_TALL(4); break;
+        case 5: TGCN_TALL(5); break;
+        case 6: TGCN_TALL(6); break;
+        case 7: TGCN_TALL(7); break;
+        default: TGCN_TALL(8); break;
+    }
+#undef TGCN_TALL
+#undef TGCN_TALL_K
+    TGCN_HIP_CHECK(hipGetLastError());
+    return TGCN_OK;
+}
+
+int check_common(const char *fn, const void *a, const void *b, const void *c, int64_t N, int k, int n) {
+    if (!a || !b || !c || N < 0 || k <= 0 || n <= 0 || k > kMaxSmall || n > kMaxSmall) {
+        set_error("%s: bad argument (N=%lld k=%d n=%d; widths must be in [1, %d])", fn, (long long)N, k, n,
+                  kMaxSmall);
+        return TGCN_E_INVALID;
+    }
+    return TGCN_OK;
+}
+
+}  // namespace
+}  // namespace tgcn
+
+extern "C" {
+
+int tgcn_gemm_nn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 int64_t N, int k, int n, tgcn_stream stream) {
+    using namespace tgcn;
+    TGCN_CHECK(check_common("tgcn_gemm_nn", A, B, C, N, k, n));
+    if (lda < k || ldb < n || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
+        set_error("tgcn_gemm_nn: need lda >= k, ldb, ldc >= n, lda %% 4 == 0 and A 16-byte aligned");
+        return TGCN_E_INVALID;
+    }
+    if (N == 0) return TGCN_OK;
+    return launch_tall<false>(A, lda, B, ldb, C, ldc, N, k, n, static_cast<hipStream_t>(stream));
+}
+
+int tgcn_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 int64_t N, int k, int n, tgcn_stream stream) {
+    using namespace tgcn;
+    TGCN_CHECK(check_common("tgcn_gemm_nt", A, B, C, N, k, n));
+    if (lda < k || ldb < k || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
+        set_error("tgcn_gemm_nt: need lda, ldb >= k, ldc >= n, lda %% 4 == 0 and A 16-byte aligned");
+        return TGCN_E_INVALID;
+    }
+    if (N == 0) return TGCN_OK;
+    return launch_tall<true>(A, lda, B, ldb, C, ldc, N, k, n, static_cast<hipStream_t>(stream));
+}
+
+size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {
+    if (N < 0 || k <= 0 || n <= 0) return 0;
+    const size_t mpad = 32 * ((k + 31) / 32), npad = 32 * ((n + 31) / 32);
+    return sizeof(float) * static_cast<size_t>(tgcn::tn_blocks(N)) * mpad * npad;
+}
+
+int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                 int64_t N, int k, int n, void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+    using namespace tgcn;
+    TGCN_CHECK(check_common("tgcn_gemm_tn", A, G, C, N, k, n));
+    if (lda < k || ldg < n || ldc < n) {
+        set_error("tgcn_gemm_tn: need lda >= k and ldg, ldc >= n");
+        return TGCN_E_INVALID;
+    }
+    const size_t need = tgcn_gemm_tn_workspace_bytes(N, k, n);
+    if (!workspace || workspace_bytes < need) {
+        set_error("tgcn_gemm_tn: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        return TGCN_E_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = tn_blocks(N);
+    const int64_t rows_per_wg = ((N + nb - 1) / nb + 1) & ~int64_t(1);  // even: steps are row pairs
+    const int nt = (n + 31) / 32, mt = (k + 31) / 32;
+    float *partial = static_cast<float *>(workspace);
+    switch (nt) {
+        case 1: k_gemm_tn_partial<1><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
+        case 2: k_gemm_tn_partial<2><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
+        case 3: k_gemm_tn_partial<3><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
+        case 4: k_gemm_tn_partial<4><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
+        default:
+            set_error("tgcn_gemm_tn: n = %d > 128 is not instantiated (use tgcn_gemm_tn with the roles of A and G swapped)", n);
+            return TGCN_E_INVALID;
+    }
+    TGCN_HIP_CHECK(hipGetLastError());
+    k_gemm_tn_reduce<<<(k * n + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mt, 32 * nt, k, n, C, ldc);
+    TGCN_HIP_CHECK(hipGetLastError());
+    return TGCN_OK;
+}
+
+}  // extern "C"

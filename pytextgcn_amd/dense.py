@@ -1,0 +1,93 @@
+"""Dense X @ W of the GCN layers on the fp32 matrix cores (libtgcn.so `tgcn_gemm_*`,
+pytextgcn_amd/csrc/dense.hip): replaces `torch.matmul(x, self.weight)` of PyG-1.6.3
+GCNConv.forward (reference call site textgcn/lib/models.py:20) and its autograd for tall-skinny
+shapes -- millions of rows, layer widths <= 256."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .plan import _stream_ptr
+
+_MAX = 256
+
+
+def supported(x: Tensor, w: Tensor) -> bool:
+    k, n = w.shape
+    kpad, npad = (k + 7) & ~7, 32 * ((n + 31) // 32)
+    kpad_t, npad_t = (n + 7) & ~7, 32 * ((k + 31) // 32)            # the backward's nt product
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
+            and k <= _MAX and n <= 128 and kpad * npad * 4 <= 160 * 1024
+            and kpad_t * npad_t * 4 <= 160 * 1024)
+
+
+def _rowmajor4(t: Tensor) -> Tensor:
+    """Unit column stride, row stride a multiple of 4 and a 16-byte aligned base (float4 loads)."""
+    if t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0:
+        if t.size(1) % 4 == 0:
+            return t.contiguous()
+        pad = (-t.size(1)) % 4
+        return torch.nn.functional.pad(t, (0, pad))[:, :t.size(1)]
+    return t
+
+
+def gemm_nn(a: Tensor, b: Tensor) -> Tensor:
+    lib = _lib.load()
+    a, b = _rowmajor4(a), b.contiguous()
+    N, k = a.shape
+    n = b.size(1)
+    c = torch.empty(N, n, dtype=torch.float32, device=a.device)
+    _lib.check(lib.tgcn_gemm_nn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
+                                c.stride(0), N, k, n, _stream_ptr(a.device)))
+    return c
+
+
+def gemm_nt(a: Tensor, b: Tensor) -> Tensor:
+    """a [N, k] @ b[n, k]^T"""
+    lib = _lib.load()
+    a, b = _rowmajor4(a), b.contiguous()
+    N, k = a.shape
+    n = b.size(0)
+    c = torch.empty(N, n, dtype=torch.float32, device=a.device)
+    _lib.check(lib.tgcn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
+                                c.stride(0), N, k, n, _stream_ptr(a.device)))
+    return c
+
+
+def gemm_tn(a: Tensor, g: Tensor) -> Tensor:
+    """a[N, k]^T @ g[N, n]"""
+    lib = _lib.load()
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    N, k = a.shape
+    n = g.size(1)
+    c = torch.empty(k, n, dtype=torch.float32, device=a.device)
+    ws_bytes = lib.tgcn_gemm_tn_workspace_bytes(N, k, n)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=a.device)
+    _lib.check(lib.tgcn_gemm_tn(a.data_ptr(), a.stride(0), g.data_ptr(), g.stride(0), c.data_ptr(),
+                                c.stride(0), N, k, n, ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
+    return c
+
+
+class _XW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor):
+        ctx.save_for_backward(x, w)
+        return gemm_nn(x.detach(), w.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w = ctx.saved_tensors
+        dx = gemm_nt(g, w) if ctx.needs_input_grad[0] else None        # g @ w^T
+        dw = gemm_tn(x, g) if ctx.needs_input_grad[1] else None        # x^T @ g
+        return dx, dw
+
+
+def xw(x: Tensor, w: Tensor) -> Tensor:
+    """x @ w with gradients, on the hand-written MFMA kernels when the shape is tall-skinny."""
+    if supported(x, w):
+        return _XW.apply(x, w)
+    return torch.matmul(x, w)

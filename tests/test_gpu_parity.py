@@ -426,3 +426,51 @@ def test_fused_training_loop_tracks_the_oracle(cuda):
             z_m = mine(gd)
         assert abs(loss.item() - l_r.item()) < 1e-4 * abs(l_r.item()), step
         assert rel_err(z_m, z_r) < 1e-3, step
+
+
+# ------------------------------------------------------------------------------------------------
+# dense X @ W on the fp32 matrix cores
+# ------------------------------------------------------------------------------------------------
+def test_mfma_gemm_identity_with_asymmetric_operand(cuda):
+    """A = I with an ASYMMETRIC B catches a transposed fragment map (a symmetric B would not)."""
+    from pytextgcn_amd import dense
+    n = 64
+    eye = torch.eye(n, device=cuda)
+    b = (torch.arange(n * 48, device=cuda, dtype=torch.float32).reshape(n, 48) % 97) - 11 * torch.arange(48, device=cuda)
+    assert torch.equal(dense.gemm_nn(eye, b), b)
+    assert torch.equal(dense.gemm_nt(eye, b.t().contiguous()), b)
+    assert torch.equal(dense.gemm_tn(eye, b), b)
+    assert torch.equal(dense.gemm_tn(b, eye[:, :40].contiguous()), b.t()[:, :40])
+
+
+@pytest.mark.parametrize("N,k,n", [(1, 1, 1), (31, 7, 3), (33, 200, 64), (1000, 64, 64), (4097, 200, 10),
+                                   (5000, 256, 128), (70000, 200, 64), (2500, 100, 5)])
+def test_mfma_gemms_match_float64(cuda, N, k, n):
+    from pytextgcn_amd import dense
+    gen = torch.Generator().manual_seed(N + k + n)
+    a = torch.randn(N, k, generator=gen)
+    b = torch.randn(k, n, generator=gen)
+    g = torch.randn(N, n, generator=gen)
+    ad, bd, gd = a.to(cuda), b.to(cuda), g.to(cuda)
+    assert rel_err(dense.gemm_nn(ad, bd), (a.double() @ b.double()).float()) < TOL
+    assert rel_err(dense.gemm_nt(gd, bd), (g.double() @ b.double().t()).float()) < TOL
+    assert rel_err(dense.gemm_tn(ad, gd), (a.double().t() @ g.double()).float()) < TOL
+    big = torch.randn(N, k + 8, generator=gen).to(cuda)                    # strided A
+    assert rel_err(dense.gemm_nn(big[:, 4:4 + k], bd), (big[:, 4:4 + k].cpu().double() @ b.double()).float()) < TOL
+
+
+def test_dense_layer_autograd_uses_the_mfma_kernels(cuda):
+    from pytextgcn_amd import dense
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3000, 200, generator=gen, requires_grad=True)
+    w = torch.randn(200, 64, generator=gen, requires_grad=True)
+    go = torch.randn(3000, 64, generator=gen)
+    (x @ w).backward(go)
+    xd, wd = x.detach().to(cuda).requires_grad_(), w.detach().to(cuda).requires_grad_()
+    assert dense.supported(xd, wd)
+    out = dense.xw(xd, wd)
+    out.backward(go.to(cuda))
+    assert rel_err(out, x @ w) < TOL and rel_err(xd.grad, x.grad) < TOL and rel_err(wd.grad, w.grad) < TOL
+    wide = torch.randn(10, 300, device=cuda)                               # outside the kernels' range
+    assert not dense.supported(wide, torch.randn(300, 8, device=cuda))
+    assert rel_err(dense.xw(wide, torch.ones(300, 8, device=cuda)), wide.cpu() @ torch.ones(300, 8)) < TOL
