@@ -146,19 +146,42 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # rehearsal knobs (one-GPU box): all ranks on one card over gloo exercises the N>1 code path
+    backend = os.environ.get("TGCN_BENCH_BACKEND", "nccl")
+    if "TGCN_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["TGCN_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pytextgcn_amd import synth
     from pytextgcn_amd.plan import GraphPlan
 
     N, E, F, C = CONFIGS[args.config]
-    g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C)     # same graph on every rank
+    if world == 1:
+        g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C)
+    else:
+        # rank 0 generates the graph and broadcasts it, so every rank partitions identical bytes
+        from pytextgcn_amd.data import Data
+        if rank == 0:
+            g0 = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features="none")
+            coo, attr = g0.edge_index.t().contiguous(), g0.edge_attr.contiguous()
+            meta = torch.tensor([g0.n_vocab], device=dev)
+            del g0
+        else:
+            coo = torch.empty(E, 2, dtype=torch.int64, device=dev)
+            attr = torch.empty(E, dtype=torch.float32, device=dev)
+            meta = torch.zeros(1, dtype=torch.int64, device=dev)
+        for t in (coo, attr, meta):
+            dist.broadcast(t, src=0)
+        g = Data(x=None, edge_index=coo.t(), edge_attr=attr, n_vocab=int(meta.item()))
     gen = torch.Generator(device=dev).manual_seed(1234)
     bias = torch.randn(F, device=dev, generator=gen)
 
