@@ -184,6 +184,88 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     }
 }
 
+// Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row): the wave splits into
+// S = 64 / G sub-groups.  In a row block every sub-group walks its OWN rows (row_begin + sub, + S,
+// ...), so S rows are gathered per wave instruction and no cross-lane reduction is needed; in a
+// long-row segment the sub-groups take entries sub, sub + S, ... and their partial sums are combined
+// with wavefront shuffles (xor G, 2G) before the carry row is written.  A sub-group loads G
+// (col,val) pairs with one coalesced instruction and hands them round with ds_bpermute.
+template <int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_sub(
+    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
+    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
+    int64_t ldc) {
+    constexpr int S = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int item_id =
+        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item_id >= n_items) return;
+    const int sub = lane / G, sl = lane % G;
+    const int nvec = F / 4;                                    // <= G (checked by the launcher)
+    const bool active = sl < nvec;
+    const int lc = (active ? sl : nvec - 1) * 4;
+    const WorkItem it = items[item_id];
+    const bool segment = it.row_end < 0;
+    float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bvec = *reinterpret_cast<const float4 *>(bias + lc);
+    const float *xl = X + lc;
+
+    // sum over entries start, start + stride, ... < end (per sub-group values)
+    auto run = [&](int start, int stride, int end) -> float4 {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t0 = start; t0 < end; t0 += G * stride) {
+            const int my = t0 + sl * stride;
+            int2 e = cv[min(my, end - 1)];                     // unconditional load, clamped index
+            if (my >= end) e.y = 0;                            // padding: weight 0
+            const int nb = min(G, (end - t0 + stride - 1) / stride);
+            for (int u0 = 0; u0 < nb; u0 += U) {
+                float4 x[U];
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int src = (sub * G + min(u0 + u, G - 1)) * 4;
+                    const int c = __builtin_amdgcn_ds_bpermute(src, e.x) & 0x7fffffff;
+                    v[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, e.y));
+                    if (u0 + u >= G) v[u] = 0.f;
+                    x[u] = *reinterpret_cast<const float4 *>(xl + int64_t(c) * ldx);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc.x = fmaf(v[u], x[u].x, acc.x);
+                    acc.y = fmaf(v[u], x[u].y, acc.y);
+                    acc.z = fmaf(v[u], x[u].z, acc.z);
+                    acc.w = fmaf(v[u], x[u].w, acc.w);
+                }
+            }
+        }
+        return acc;
+    };
+
+    if (segment) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it.nnz_begin + sub < it.nnz_end) acc = run(it.nnz_begin + sub, S, it.nnz_end);
+#pragma unroll
+        for (int off = G; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        const int slot = -it.row_end - 1;
+        if (sub == 0 && active) *reinterpret_cast<float4 *>(carry + int64_t(slot) * ldc + lc) = acc;
+    } else {
+        for (int r = it.row_begin + sub; r < it.row_end; r += S) {
+            const int b = rowptr[r], e = rowptr[r + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < e) acc = run(b, 1, e);
+            if (active)
+                *reinterpret_cast<float4 *>(Y + int64_t(r) * ldy + lc) =
+                    make_float4(acc.x + bvec.x, acc.y + bvec.y, acc.z + bvec.z, acc.w + bvec.w);
+        }
+    }
+}
+
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
 template <int VEC>
@@ -233,6 +315,14 @@ int variant_from_env() {
     return v;
 }
 
+bool narrow_from_env() {
+    static const bool on = [] {
+        const char *s = std::getenv("TGCN_SPMM_NARROW");
+        return s ? std::atoi(s) != 0 : true;
+    }();
+    return on;
+}
+
 template <int VEC>
 int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
                int64_t ldy, float *carry, hipStream_t stream) {
@@ -240,6 +330,16 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
     const int64_t ldc = round_up4(F);
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
+        if (VEC == 4 && F <= 128 && narrow_from_env()) {
+            // narrow feature rows (the layer-2 width C): sub-group kernel
+            if (F <= 64)
+                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F,
+                                                           bias, Y, ldy, carry, ldc);
+            else
+                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F,
+                                                           bias, Y, ldy, carry, ldc);
+            TGCN_HIP_CHECK(hipGetLastError());
+        } else {
 #define TGCN_LAUNCH(UU, PP)                                                                      \
     k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, \
                                                          F, bias, Y, ldy, carry, ldc)
@@ -260,6 +360,7 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
         }
 #undef TGCN_LAUNCH
         TGCN_HIP_CHECK(hipGetLastError());
+        }
     }
     if (b.n_fix > 0) {
         dim3 grid(b.n_fix, tiles);
