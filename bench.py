@@ -31,6 +31,7 @@ CONFIGS = {
     # name: (n_nodes, n_edges, F, n_classes)
     "c2": (100_000, 2_000_000, 200, 64),
     "c4": (2_000_000, 50_000_000, 200, 64),
+    "c3": (1_000_000, 24_000_000, 200, 219),     # DBpedia-shaped: V = 30 k, 219 classes (l3)
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
@@ -165,13 +166,14 @@ def main():
     from pytextgcn_amd.plan import GraphPlan
 
     N, E, F, C = CONFIGS[args.config]
+    gen_kw = dict(vocab_frac=0.03, doc_word_share=0.9) if args.config == "c3" else {}
     if world == 1:
-        g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C)
+        g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, **gen_kw)
     else:
         # rank 0 generates the graph and broadcasts it, so every rank partitions identical bytes
         from pytextgcn_amd.data import Data
         if rank == 0:
-            g0 = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features="none")
+            g0 = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features="none", **gen_kw)
             coo, attr = g0.edge_index.t().contiguous(), g0.edge_attr.contiguous()
             meta = torch.tensor([g0.n_vocab], device=dev)
             del g0

@@ -474,3 +474,66 @@ def test_dense_layer_autograd_uses_the_mfma_kernels(cuda):
     wide = torch.randn(10, 300, device=cuda)                               # outside the kernels' range
     assert not dense.supported(wide, torch.randn(300, 8, device=cuda))
     assert rel_err(dense.xw(wide, torch.ones(300, 8, device=cuda)), wide.cpu() @ torch.ones(300, 8)) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# the remaining BASELINE.json shapes as parity cases: c3 (DBpedia-shaped) and c5 (power law, h = 256)
+# ------------------------------------------------------------------------------------------------
+def _sampled_row_check(plan, x, y, rows, tol=TOL):
+    rp, col, val = plan.export_csr()
+    for r in rows:
+        s, e = rp[r].item(), rp[r + 1].item()
+        ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
+        assert rel_err(y[r], ref.float()) < tol, r
+    return rp
+
+
+def test_config_c3_dbpedia_shaped_graph(cuda):
+    """~1 M nodes with a 30 k vocabulary (flat_dbpedia.py: min_df=100, max_df=.4 keep the vocabulary
+    small), h = 200; the real DBpedia CSVs are not in the reference tree."""
+    N, E, F = 1_000_000, 24_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, vocab_frac=0.03, doc_word_share=0.9, features="none")
+    assert g.n_vocab == 30_000
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    assert plan.symmetric and plan.nnz == E + N
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    b = torch.randn(F, device=cuda, generator=gen)
+    rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N)
+    R = 40_000                                               # all word rows (the long ones) + 10 k docs
+    ref = csr_oracle.csr_spmm(rp[:R + 1], c[:rp[R]], v[:rp[R]], x.cpu(), b.cpu(), acc64=True)
+    out = plan.spmm(x, b)
+    assert rel_err(out[:R], ref) < TOL
+    deg = (rp[1:] - rp[:-1])
+    rows = torch.cat([deg.topk(4).indices, torch.randint(R, N, (100,))]).tolist()
+    _sampled_row_check(plan, x, out - b, rows)
+
+
+def test_config_c5_power_law_graph_h256(cuda):
+    """8 M nodes / 200 M edges, degree ~ power law, h = 256 (BASELINE.json configs[4]); no hub/regular
+    structure, asserted through size-independent properties and sampled rows."""
+    N, E, F = 8_000_000, 200_000_000, 256
+    g = synth.power_law_graph(N, E, seed=44, device=cuda)
+    assert g.edge_index.shape == (2, E)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    del g
+    assert plan.symmetric and plan.nnz == E + N
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    y = plan.spmm(x)
+    rp, col, val = plan.export_csr()
+    deg = (rp[1:] - rp[:-1]).long()
+    assert deg.max().item() > 10_000                          # heavy tail: long rows are split
+    assert plan.stats()["long_rows"] > 0
+    rows = torch.cat([deg.topk(6).indices, torch.randint(0, N, (150,), device=cuda, generator=gen)]).tolist()
+    for r in rows:
+        s, e = rp[r].item(), rp[r + 1].item()
+        ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
+        assert rel_err(y[r], ref.float()) < TOL, r
+    del rp, col, val, deg
+    z = torch.randn(N, F, device=cuda, generator=gen)
+    lhs = (y.double() * z.double()).sum().item()              # <Mx, z> = <x, M^T z>
+    rhs = (x.double() * plan.spmm(z, transpose=True).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs)) + 1e-2
+    two = plan.spmm(2 * x)
+    assert rel_err(two, 2 * y) < TOL
