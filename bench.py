@@ -138,6 +138,51 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3):
     return sorted(times)[len(times) // 2]
 
 
+def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3):
+    """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
+    W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
+    summed with one all-reduce; predictions of the owned rows go to the host."""
+    import pytextgcn_amd as pkg
+    from pytextgcn_amd.sharded import ShardedGCN, sharded_cross_entropy
+    gen = torch.Generator(device=dev).manual_seed(7)
+    y_full = torch.randint(0, n_classes, (N,), device=dev, generator=gen)
+    u = torch.rand(N, device=dev, generator=gen)
+    is_doc = ~sg.part.hub_mask
+    y_l = sg.scatter_rows(y_full)
+    train_l = sg.scatter_rows(is_doc & (u < 0.8))
+    val_l = sg.scatter_rows(is_doc & (u >= 0.8) & (u < 0.9))
+    del y_full, u
+    model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5).to(dev)
+    with torch.no_grad():
+        model.weights[0].uniform_(-0.0017, 0.0017)            # glorot bound of an N x h matrix
+    opt = pkg.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
+    times = []
+    for rep in range(reps + 1):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train()
+        loss = sharded_cross_entropy(sg, model(), y_l, train_l)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        model.sync_grads()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            logits = model()
+            sharded_cross_entropy(sg, logits, y_l, val_l)
+            pred_val = logits[val_l].argmax(1).cpu().numpy()
+            pred_train = logits[train_l].argmax(1).cpu().numpy()
+        loss.item()
+        dist.barrier()
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) * 1e3)
+    t = torch.tensor([sorted(times)[len(times) // 2]], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +308,9 @@ def main():
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
 
     epoch_ms = epoch_ms_fused = None
+    if (world > 1 or force_sharded) and not args.no_epoch:
+        del x, gout
+        epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = epoch_time_ms(g, F, C, fused=False)

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
     }
 }
 
-// Tuning knob for experiments (tools/sweep_spmm.py): TGCN_SPMM_VARIANT = "<U>:<POLICY>".
+// A/B knob (tools/sweep_spmm.py): TGCN_SPMM_VARIANT = "8:0" selects the kernel without cache hints.
+// Other unroll depths (4, 16) and hint sets were measured within +-2 % and dropped.
 int variant_from_env() {
     static const int v = [] {
         const char *s = std::getenv("TGCN_SPMM_VARIANT");
@@ -345,15 +346,8 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
                                                          F, bias, Y, ldy, carry, ldc)
         if constexpr (VEC == 4) {
             switch (variant_from_env()) {
-                case 4 * 16 + 0: TGCN_LAUNCH(4, 0); break;
-                case 16 * 16 + 0: TGCN_LAUNCH(16, 0); break;
-                case 8 * 16 + 1: TGCN_LAUNCH(8, 1); break;
-                case 8 * 16 + 2: TGCN_LAUNCH(8, 2); break;
-                case 8 * 16 + 4: TGCN_LAUNCH(8, 4); break;
-                case 8 * 16 + 7: TGCN_LAUNCH(8, 7); break;
-                case 16 * 16 + 3: TGCN_LAUNCH(16, 3); break;
-                case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;
-                default: TGCN_LAUNCH(8, 3); break;
+                case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;   // plain loads / stores (for A/B runs)
+                default: TGCN_LAUNCH(8, 3); break;           // streams non-temporal (measured best)
             }
         } else {
             TGCN_LAUNCH(8, 0);

@@ -30,7 +30,7 @@ def _mask_count(mask: Tensor) -> int:
     return hit
 
 
-def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool):
+def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count=None):
     lib = _lib.load()
     _require_cuda(logits, "logits")
     if logits.dtype != torch.float32 or logits.dim() != 2:
@@ -44,7 +44,8 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool):
         logits = logits.contiguous()
     target = target.long().contiguous()
     mask = mask.contiguous()
-    count = _mask_count(mask)
+    if count is None:
+        count = _mask_count(mask)
     inv = 1.0 / count if count else float("nan")          # torch: mean over an empty selection = nan
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device) if want_grad else None
@@ -60,18 +61,20 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool):
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor):
-        loss, dlogits = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0])
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count):
+        loss, dlogits = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count)
         ctx.save_for_backward(dlogits)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         (dlogits,) = ctx.saved_tensors
-        return dlogits.mul_(grad_out), None, None          # dlogits is ours: scale in place
+        return dlogits.mul_(grad_out), None, None, None    # dlogits is ours: scale in place
 
 
-def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor) -> Tensor:
+def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor, count=None) -> Tensor:
+    """`count` overrides the divisor (default: rows selected by `mask`); the sharded path passes the
+    GLOBAL count so that per-rank losses and gradients add up to the single-device ones."""
     if logits.requires_grad and torch.is_grad_enabled():
-        return _MaskedCE.apply(logits, target, mask)
-    return _launch(logits, target, mask, False)[0]
+        return _MaskedCE.apply(logits, target, mask, count)
+    return _launch(logits, target, mask, False, count)[0]

@@ -62,6 +62,14 @@ class HipEngine:
         from .plan import colsum
         return colsum(g)
 
+    def xw(self, x: Tensor, w: Tensor) -> Tensor:
+        from . import dense
+        return dense.xw(x, w)                 # fp32 MFMA kernels, with autograd
+
+    def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int) -> Tensor:
+        from .functional import masked_cross_entropy
+        return masked_cross_entropy(logits, y, mask, count=count)
+
 
 class Partition:
     """Node -> (owner rank, slot) assignment; a pure function of (graph, world, hubs), so every
@@ -295,7 +303,9 @@ class ShardedGCN(nn.Module):
         x = sharded_propagate(self.sg, self.weights[0], self.biases[0])
         for i in range(1, len(self.weights)):
             x = nn.functional.dropout(x, p=self.dropout, training=self.training)
-            x = sharded_propagate(self.sg, torch.matmul(x, self.weights[i]), self.biases[i])
+            xw = self.sg.engine.xw(x, self.weights[i]) if hasattr(self.sg.engine, "xw") \
+                else torch.matmul(x, self.weights[i])
+            x = sharded_propagate(self.sg, xw, self.biases[i])
         return x
 
     def sync_grads(self) -> None:
@@ -310,10 +320,20 @@ def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tenso
     local sum of row losses divided by the global row count, so that summing the replicated
     gradients over ranks reproduces the single-device gradient.  Returns this rank's share of the
     loss; all-reduce it (sum) for the value the reference prints."""
-    cnt = mask_local.sum().to(torch.float32).reshape(1)
-    dist.all_reduce(cnt, group=sg.group)
+    key = (mask_local.data_ptr(), mask_local._version)
+    cached = getattr(sg, "_count_cache", {}).get(key)
+    if cached is None:                                   # masks are static: count (and sync) once
+        c = mask_local.sum().to(torch.float64).reshape(1)
+        dist.all_reduce(c, group=sg.group)
+        cached = int(c.item())
+        if not hasattr(sg, "_count_cache"):
+            sg._count_cache = {}
+        sg._count_cache[key] = cached
+    if hasattr(sg.engine, "masked_ce"):                  # fused HIP kernel, global divisor
+        return sg.engine.masked_ce(logits_local, y_local, mask_local, cached)
+    cnt = torch.tensor(float(cached), device=logits_local.device)
     if bool(mask_local.any()):
         part = nn.functional.cross_entropy(logits_local[mask_local], y_local[mask_local], reduction="sum")
     else:
         part = logits_local.sum() * 0.0
-    return part / cnt.squeeze(0)
+    return part / cnt
