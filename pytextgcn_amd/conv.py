@@ -83,6 +83,34 @@ def is_sparse_identity(x: Tensor) -> bool:
     return ok
 
 
+# [I_N | H] features of the hierarchical scripts (text2graph.py:237-241; perlevel_amazon.py:122,156):
+# X @ W = W[:N] + H @ W[N:], with H the sparse N x F_h hierarchy block.
+_SPLIT_CACHE: dict = {}
+
+
+def split_identity_block(x: Tensor):
+    """For a sparse [N, N + F_h] matrix whose first N columns are the identity, return the sparse
+    [N, F_h] remainder (None when x does not have that shape).  Cached per tensor object."""
+    if not x.is_sparse or x.size(1) <= x.size(0):
+        return None
+    hit = _SPLIT_CACHE.get(id(x))
+    if hit is not None and hit[0]() is x:
+        return hit[1]
+    n = x.size(0)
+    xc = x if x.is_coalesced() else x.coalesce()
+    idx, val = xc.indices(), xc.values()
+    left = idx[1] < n
+    ok = bool((int(left.sum()) == n) and bool(((idx[0][left] == idx[1][left]) & (val[left] == 1)).all()))
+    rest = None
+    if ok:
+        r = ~left
+        rest = torch.sparse_coo_tensor(torch.stack([idx[0][r], idx[1][r] - n]), val[r],
+                                       (n, x.size(1) - n)).coalesce()
+    key = id(x)
+    _SPLIT_CACHE[key] = (weakref.ref(x, lambda _, k=key: _SPLIT_CACHE.pop(k, None)), rest)
+    return rest
+
+
 def glorot_(t: Tensor) -> Tensor:
     a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
     with torch.no_grad():
@@ -121,7 +149,13 @@ class GCNConv(nn.Module):
             if x.size(1) != self.in_channels:
                 raise ValueError(f"x has {x.size(1)} features, the layer expects {self.in_channels}")
             # layer 1 of TextGCN: one-hot features, so X @ W1 is W1 (and dW1 = dXW, no GEMM)
-            xw = self.weight if is_sparse_identity(x) else torch.sparse.mm(x, self.weight)
+            if is_sparse_identity(x):
+                xw = self.weight
+            else:
+                h = split_identity_block(x)
+                n = x.size(0)
+                xw = (self.weight[:n] + torch.sparse.mm(h, self.weight[n:]) if h is not None
+                      else torch.sparse.mm(x, self.weight))
         else:
             xw = dense.xw(x, self.weight)     # fp32 MFMA kernels for tall-skinny shapes
         return propagate(plan, xw, self.bias)

@@ -537,3 +537,32 @@ def test_config_c5_power_law_graph_h256(cuda):
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs)) + 1e-2
     two = plan.spmm(2 * x)
     assert rel_err(two, 2 * y) < TOL
+
+
+def test_hierarchy_feature_block_fast_path(cuda):
+    """x = [I_N | H] (text2graph.py:237-241, used by perlevel_amazon.py:122): X @ W = W[:N] + H @ W[N:]."""
+    from pytextgcn_amd.conv import split_identity_block
+    N, Fh, C = 900, 7, 5
+    g = synth.word_doc_graph(N, 9000, seed=21, n_classes=C)
+    V = g.n_vocab
+    gen = torch.Generator().manual_seed(2)
+    hf = torch.zeros(N, Fh)
+    hf[V:] = torch.rand(N - V, Fh, generator=gen) * (torch.rand(N - V, Fh, generator=gen) < 0.5)
+    ar = torch.arange(N)
+    nz = hf.nonzero()
+    x = torch.sparse_coo_tensor(torch.cat([torch.stack([ar, ar]), torch.stack([nz[:, 0], nz[:, 1] + N])], 1),
+                                torch.cat([torch.ones(N), hf[nz[:, 0], nz[:, 1]]]), (N, N + Fh)).coalesce()
+    g.x = x
+    torch.manual_seed(8)
+    ref = O.GCNOracle(N + Fh, C, n_hidden_gcn=24, dropout=0.0)
+    mine = pkg.GCN(N + Fh, C, n_hidden_gcn=24, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    rest = split_identity_block(gd.x)
+    assert rest is not None and tuple(rest.shape) == (N, Fh)
+    assert split_identity_block(torch.eye(4).to_sparse().to(cuda)) is None
+    lo_r, lo_m = ref(g), mine(gd)
+    assert rel_err(lo_m, lo_r) < TOL
+    lo_r[g.train_mask].sum().backward(), lo_m[gd.train_mask].sum().backward()
+    assert rel_err(mine.layers[0].weight.grad, ref.layers[0].weight.grad) < 5 * TOL
