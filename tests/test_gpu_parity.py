@@ -566,3 +566,60 @@ def test_hierarchy_feature_block_fast_path(cuda):
     assert rel_err(lo_m, lo_r) < TOL
     lo_r[g.train_mask].sum().backward(), lo_m[gd.train_mask].sum().backward()
     assert rel_err(mine.layers[0].weight.grad, ref.layers[0].weight.grad) < 5 * TOL
+
+
+def test_compute_entry_points_are_hipgraph_capturable(cuda):
+    """include/tgcn.h promises that the compute calls only enqueue on the caller's stream (no
+    allocation, no synchronisation): capture a forward/backward/optimizer step of the operators in a
+    HIP graph and replay it."""
+    from pytextgcn_amd import dense
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.optim import Adam
+    N, F, C = 20000, 200, 64
+    g = synth.word_doc_graph(N, 300000, seed=9, device=cuda, n_classes=C)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    w1 = torch.randn(N, F, device=cuda).mul_(0.01).requires_grad_()
+    w2 = torch.randn(F, C, device=cuda).mul_(0.1).requires_grad_()
+    b1 = torch.zeros(F, device=cuda)
+    opt = Adam([w1, w2], lr=0.01, amsgrad=True)
+
+    def step():
+        h = plan.spmm(w1.detach(), b1)
+        z = plan.spmm(dense.gemm_nn(h, w2.detach()))
+        lg = z.detach().requires_grad_()
+        loss = masked_cross_entropy(lg, g.y, g.train_mask)
+        loss.backward()
+        dxw2 = plan.spmm(lg.grad, transpose=True)
+        w2.grad = dense.gemm_tn(h, dxw2)
+        w1.grad = plan.spmm(dense.gemm_nt(dxw2, w2.detach()), transpose=True)
+        opt.step()
+        return loss.detach()
+
+    ref_w1, ref_w2 = w1.detach().clone(), w2.detach().clone()
+
+    def reset():
+        with torch.no_grad():
+            w1.copy_(ref_w1), w2.copy_(ref_w2)
+        for st in opt.state.values():
+            st["step"] = 0
+            for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                st[k].zero_()
+
+    loss_eager = step().item()                                  # eager step 1 (also creates opt state)
+    w1_eager, w2_eager = w1.detach().clone(), w2.detach().clone()
+    # the fused Adam takes the step count as a host scalar, so a captured graph replays ONE fixed
+    # step number: capture step 1 and compare with the eager step 1
+    reset()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = step()
+    torch.cuda.current_stream().wait_stream(side)
+    reset()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert out.item() == loss_eager                             # deterministic kernels: bitwise
+    assert torch.equal(w1.detach(), w1_eager) and torch.equal(w2.detach(), w2_eager)
+    assert not torch.equal(w1.detach(), ref_w1)

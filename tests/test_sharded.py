@@ -62,3 +62,7 @@ def test_world2_hub_partition_and_allgather_partition():
 
 def test_world3_asymmetric_graph_and_uneven_shards():
     run(3, ["asym", "wordoc"])
+
+
+def test_world4_hub_partition():
+    run(4, ["wordoc"])
