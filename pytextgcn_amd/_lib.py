@@ -68,11 +68,12 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("TGCN_LIB_PATH", LIB_PATH)      # A/B runs against another build of the library
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            f"{path} is missing: the HIP extension has not been built "
             "(run `python -m pytextgcn_amd.build`); pytextgcn_amd has no CPU fallback")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the library lacks a declared symbol
         fn.restype = res

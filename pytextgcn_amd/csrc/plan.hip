@@ -242,30 +242,12 @@ __global__ void k_block_cuts(const int32_t *__restrict__ long_rows, int n_long,
     const int64_t target = int64_t(j) * col_block;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if ((cv[mid].x & 0x7fffffff) < target)
+        if (cv[mid].x < target)
             lo = mid + 1;
         else
             hi = mid;
     }
     pos[idx] = lo;
-}
-
-// Column reference counts, then the COLD flag (sign bit of the stored column id) on every entry
-// whose column is gathered fewer than `cold_count` times per SpMM: the kernel loads those rows
-// with the non-temporal hint so that they do not push the frequently gathered rows out of L2.
-__global__ void k_col_hist(const int2 *__restrict__ cv, int64_t nnz, int32_t *__restrict__ count) {
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride)
-        atomicAdd(&count[cv[j].x], 1);
-}
-
-__global__ void k_mark_cold(int2 *__restrict__ cv, int64_t nnz, const int32_t *__restrict__ count,
-                            int cold_count) {
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
-        const int c = cv[j].x;
-        if (count[c] < cold_count) cv[j].x = c | int(0x80000000u);
-    }
 }
 
 // Tuning knobs (tools/sweep_spmm.py); the defaults are the measured best on config c4.
@@ -274,7 +256,6 @@ struct Knobs {
     int min_piece;  // merge adjacent column blocks of a row until a piece has this many entries
     int order;      // 0 = row order, 1 = segments first, 2 = row blocks first, 3 = interleaved,
                     // 4 = interleaved in XCD-affine queues (column block j -> XCD j % 8)
-    int cold_count; // columns referenced fewer times than this are gathered non-temporally; 0 = off
 };
 
 Knobs knobs_from_env() {
@@ -286,7 +267,6 @@ Knobs knobs_from_env() {
     k.col_block = geti("TGCN_COL_BLOCK", 8192);
     k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 64));
     k.order = geti("TGCN_ITEM_ORDER", 3);
-    k.cold_count = geti("TGCN_COLD_COUNT", 0);
     return k;
 }
 
@@ -325,17 +305,6 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
                                   hipMemcpyDeviceToHost, stream));
     TGCN_HIP_CHECK(hipStreamSynchronize(stream));
     const int32_t n_rows = static_cast<int32_t>(b.n_rows);
-    if (kn.cold_count > 0 && b.nnz > 0) {
-        DevBuf count;
-        TGCN_CHECK(count.alloc(sizeof(int32_t) * b.n_cols));
-        TGCN_HIP_CHECK(hipMemsetAsync(count.p, 0, sizeof(int32_t) * b.n_cols, stream));
-        k_col_hist<<<grid_for(b.nnz, kThreads, 8192), kThreads, 0, stream>>>(b.cv, b.nnz, count.as<int32_t>());
-        TGCN_HIP_CHECK(hipGetLastError());
-        k_mark_cold<<<grid_for(b.nnz, kThreads, 8192), kThreads, 0, stream>>>(b.cv, b.nnz, count.as<int32_t>(),
-                                                                           kn.cold_count);
-        TGCN_HIP_CHECK(hipGetLastError());
-        TGCN_HIP_CHECK(hipStreamSynchronize(stream));
-    }
 
     // pass 1: row blocks and the list of long rows
     std::vector<WorkItem> blocks;
@@ -818,7 +787,7 @@ __global__ void k_export(const int2 *__restrict__ cv, int64_t nnz, int32_t *col,
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nnz; j += stride) {
         const int2 p = cv[j];
-        if (col) col[j] = p.x & 0x7fffffff;
+        if (col) col[j] = p.x;
         if (val) val[j] = __int_as_float(p.y);
     }
 }

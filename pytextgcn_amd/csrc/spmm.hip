@@ -69,28 +69,21 @@ __device__ __forceinline__ float readlane_f(int bits, int lane) {
 
 constexpr int kWavesPerBlock = 4;
 
-// grid.x = ceil(n_items / 4), grid.y = column tiles of 64*VEC floats
-// POLICY bits (cache hints, chosen by measurement): 1 = non-temporal (col,val) stream,
-// 2 = non-temporal result stores, 4 = non-temporal gathered rows
+// One work item on one wavefront.  POLICY bits (cache hints, chosen by measurement): 1 = non-temporal
+// (col,val) stream, 2 = non-temporal result stores.  The gathered rows themselves always use plain
+// loads: a non-temporal hint on them destroys the L2 / Infinity-Cache re-use (7.5 ms instead of 4.4),
+// and even a per-entry "cold column" hint behind a branch cost more than it saved.
 template <int VEC, int U, int POLICY>
-__global__ __launch_bounds__(256) void k_spmm_gather(
-    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
-    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
-    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
-    int64_t ldc) {
+__device__ __forceinline__ void spmm_item(
+    const WorkItem it, const int lane, const int col0, const int F,
+    const int32_t *__restrict__ rowptr, const int2 *__restrict__ cv, const float *__restrict__ X,
+    const int64_t ldx, const float *__restrict__ bias, float *__restrict__ Y, const int64_t ldy,
+    float *__restrict__ carry, const int64_t ldc) {
     using V = Vec<VEC>;
     using vec_t = typename V::type;
-    const int lane = threadIdx.x & 63;
-    const int item_id =
-        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (item_id >= n_items) return;
-
-    const int col0 = blockIdx.y * (64 * VEC);
     const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;  // vectors in this column tile
     const bool active = lane < nvec;
     const int lc = col0 + (active ? lane : nvec - 1) * VEC;      // idle lanes shadow the last one
-
-    const WorkItem it = items[item_id];
     const int nnz_end = it.nnz_end;
     const bool segment = it.row_end < 0;
 
@@ -147,17 +140,9 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int cf = readlane_i(mine.x, j0 + u);
-                const int c = cf & 0x7fffffff;          // sign bit = "cold column" (plan.hip)
+                const int c = readlane_i(mine.x, j0 + u);
                 v[u] = readlane_f(mine.y, j0 + u);
-                if constexpr ((POLICY & 4) != 0) {
-                    x[u] = V::load_nt(xl + int64_t(c) * ldx);
-                } else {
-                    if (cf < 0)
-                        x[u] = V::load_nt(xl + int64_t(c) * ldx);
-                    else
-                        x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
-                }
+                x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -182,6 +167,21 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
             ++r;
         }
     }
+}
+
+// grid.x = ceil(n_items / 4), grid.y = column tiles of 64*VEC floats; one item per wavefront
+template <int VEC, int U, int POLICY>
+__global__ __launch_bounds__(256) void k_spmm_gather(
+    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
+    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
+    int64_t ldc) {
+    const int lane = threadIdx.x & 63;
+    const int item_id =
+        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item_id >= n_items) return;
+    spmm_item<VEC, U, POLICY>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, bias,
+                              Y, ldy, carry, ldc);
 }
 
 // Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row): the wave splits into
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int src = (sub * G + min(u0 + u, G - 1)) * 4;
-                    const int c = __builtin_amdgcn_ds_bpermute(src, e.x) & 0x7fffffff;
+                    const int c = __builtin_amdgcn_ds_bpermute(src, e.x);
                     v[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, e.y));
                     if (u0 + u >= G) v[u] = 0.f;
                     x[u] = *reinterpret_cast<const float4 *>(xl + int64_t(c) * ldx);
@@ -339,22 +339,21 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
             else
                 k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F,
                                                            bias, Y, ldy, carry, ldc);
-            TGCN_HIP_CHECK(hipGetLastError());
         } else {
 #define TGCN_LAUNCH(UU, PP)                                                                      \
-    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, \
-                                                         F, bias, Y, ldy, carry, ldc)
-        if constexpr (VEC == 4) {
-            switch (variant_from_env()) {
-                case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;   // plain loads / stores (for A/B runs)
-                default: TGCN_LAUNCH(8, 3); break;           // streams non-temporal (measured best)
+    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F, \
+                                                         bias, Y, ldy, carry, ldc)
+            if constexpr (VEC == 4) {
+                switch (variant_from_env()) {
+                    case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;   // plain loads / stores (for A/B runs)
+                    default: TGCN_LAUNCH(8, 3); break;           // streams non-temporal (measured best)
+                }
+            } else {
+                TGCN_LAUNCH(8, 0);
             }
-        } else {
-            TGCN_LAUNCH(8, 0);
-        }
 #undef TGCN_LAUNCH
-        TGCN_HIP_CHECK(hipGetLastError());
         }
+        TGCN_HIP_CHECK(hipGetLastError());
     }
     if (b.n_fix > 0) {
         dim3 grid(b.n_fix, tiles);

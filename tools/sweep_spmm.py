@@ -70,14 +70,9 @@ if __name__ == "__main__":
     elif mode == "phases":
         phases()
     elif mode == "variants":
-        settings = [dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="64"),
-                    dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:3"),
-                    dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="128", TGCN_SPMM_VARIANT="8:3"),
-                    dict(TGCN_COL_BLOCK="8192", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:3"),
-                    dict(TGCN_COL_BLOCK="4096", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:3"),
-                    dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:1"),
-                    dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:2"),
-                    dict(TGCN_COL_BLOCK="16384", TGCN_MIN_PIECE="64", TGCN_SPMM_VARIANT="8:3", TGCN_COLD_COUNT="16")]
+        settings = [dict(TGCN_LIB_PATH=os.path.join(ROOT, "pytextgcn_amd/lib/libtgcn_old.so")), dict(),
+                    dict(TGCN_SPMM_VARIANT="8:0"), dict(TGCN_COL_BLOCK="4096"), dict(TGCN_COL_BLOCK="16384"),
+                    dict(TGCN_ITEM_WEIGHT="1024"), dict(TGCN_ITEM_WEIGHT="384")]
         for kv in settings:
             env = dict(os.environ, **kv)
             r = subprocess.run([sys.executable, __file__, "one", "c4"], env=env, capture_output=True, text=True)
