@@ -83,3 +83,28 @@ def test_product_path_has_no_cpu_fallback():
         m(g)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.colsum(torch.ones(4, 4))
+
+
+def test_fused_training_helpers_refuse_cpu_tensors():
+    from pytextgcn_amd import dense, functional, graphbuilder, optim
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        functional.masked_cross_entropy(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long),
+                                        torch.ones(4, dtype=torch.bool))
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        optim.Adam([p]).step()
+    with pytest.raises(ValueError):
+        optim.Adam([p], lr=-1.0)
+    assert not dense.supported(torch.zeros(4, 8), torch.zeros(8, 2))           # CPU tensors: torch.matmul
+    if not torch.cuda.is_available():
+        import numpy as np
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            graphbuilder.compute_word_word_edges(np.zeros((1, 2), dtype=np.int32), 3, 1, 2, 2)
+
+
+def test_sharded_module_imports_without_a_process_group():
+    from pytextgcn_amd import sharded
+    g = synth.word_doc_graph(400, 3000, seed=2)
+    p = sharded.Partition(g.edge_index, 400, 3, torch.arange(400) < g.n_vocab)
+    assert p.n_local == p.hp + p.rp and p.hp * 3 >= g.n_vocab
