@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The flat_amazon.py loop on several GPUs of one node: one process per GPU, RCCL underneath.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        examples/flat_synthetic_multigpu.py [--docs 20000] [--epochs 30] [--backend nccl]
+
+Rank 0 builds the graph (Text2GraphTransformer) and broadcasts it; every rank then owns a block of
+rows of the operator, of W1 / H1 / logits and of the Adam state (pytextgcn_amd.sharded).  The word
+nodes are the replicated "hubs"; document features never leave their owner.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytextgcn_amd import Text2GraphTransformer, optim, synth  # noqa: E402
+from pytextgcn_amd.sharded import ShardedGCN, ShardedGraph, sharded_cross_entropy  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--docs", type=int, default=20000)
+p.add_argument("--epochs", type=int, default=30)
+p.add_argument("--backend", default="nccl")
+p.add_argument("--device", type=int, default=None, help="force a device index (several ranks on one GPU: gloo only)")
+args = p.parse_args()
+
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+dev_index = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", 0))
+th.cuda.set_device(dev_index)
+dev = th.device("cuda", dev_index)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+if args.backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+seed, lr, dropout, n_classes = 44, 0.05, 0.5, 6
+th.manual_seed(seed + rank)                        # dropout streams differ per rank
+if rank == 0:
+    docs, y = synth.synthetic_corpus(args.docs, 4000, n_classes=n_classes, seed=seed)
+    perm = np.random.default_rng(seed).permutation(len(docs))
+    g = Text2GraphTransformer(min_df=5, window_size=20, rm_stopwords=False).fit_transform(
+        docs, y, test_idx=perm[:len(docs) // 10], val_idx=perm[len(docs) // 10:len(docs) // 5])
+    meta = th.tensor([g.x.shape[0], g.edge_index.shape[1], g.n_vocab], device=dev)
+else:
+    meta = th.zeros(3, dtype=th.long, device=dev)
+dist.broadcast(meta, 0)
+N, E, V = (int(v) for v in meta.tolist())
+coo = g.edge_index.t().contiguous().to(dev) if rank == 0 else th.empty(E, 2, dtype=th.long, device=dev)
+attr = g.edge_attr.to(dev) if rank == 0 else th.empty(E, dtype=th.float32, device=dev)
+labels = g.y.to(dev) if rank == 0 else th.empty(N, dtype=th.long, device=dev)
+masks = th.stack([g.train_mask, g.val_mask, g.test_mask]).to(dev).to(th.uint8) if rank == 0 \
+    else th.empty(3, N, dtype=th.uint8, device=dev)
+for t in (coo, attr, labels, masks):
+    dist.broadcast(t, 0)
+
+sg = ShardedGraph(coo.t(), attr, N, hubs=th.arange(N, device=dev) < V)
+gcn = ShardedGCN(sg, N, n_classes, n_hidden_gcn=100, dropout=dropout).to(dev)
+with th.no_grad():                                  # glorot over the FULL (N, h) matrix
+    a = (6.0 / (N + 100)) ** 0.5
+    gcn.weights[0].uniform_(-a, a).mul_(sg.real.unsqueeze(1))
+y_l = sg.scatter_rows(labels)
+train_l, val_l, test_l = (sg.scatter_rows(masks[i].bool()) for i in range(3))
+optimizer = optim.Adam(gcn.parameters(), lr=lr, amsgrad=True)
+
+
+def accuracy(logits, mask):
+    hit = th.stack([(logits[mask].argmax(1) == y_l[mask]).sum(), mask.sum()]).double()
+    dist.all_reduce(hit)
+    return (hit[0] / hit[1]).item()
+
+
+th.cuda.synchronize()
+t0 = time.time()
+for epoch in range(args.epochs):
+    gcn.train()
+    loss = sharded_cross_entropy(sg, gcn(), y_l, train_l)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    gcn.sync_grads()
+    optimizer.step()
+    gcn.eval()
+    with th.no_grad():
+        logits = gcn()
+        acc_val = accuracy(logits, val_l)
+    total = loss.detach().clone()
+    dist.all_reduce(total)
+    if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
+        print(f"[{epoch + 1:3d}] loss: {total.item(): .3f}, val accuracy: {acc_val: .3f}", flush=True)
+th.cuda.synchronize()
+with th.no_grad():
+    acc_test = accuracy(gcn(), test_l)
+if rank == 0:
+    print(f"{world} rank(s): {args.epochs} epochs in {time.time() - t0:.2f} s; test accuracy {acc_test:.3f}")
+dist.barrier()
+dist.destroy_process_group()

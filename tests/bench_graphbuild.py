@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this script lives in tests/: it uses the CPU oracle)
 sys.path.insert(0, ROOT)
 from oracle import graphbuilder_py as G  # noqa: E402
 from pytextgcn_amd import graphbuilder, synth, text2graph  # noqa: E402
