@@ -623,3 +623,58 @@ def test_compute_entry_points_are_hipgraph_capturable(cuda):
     assert out.item() == loss_eager                             # deterministic kernels: bitwise
     assert torch.equal(w1.detach(), w1_eager) and torch.equal(w2.detach(), w2_eager)
     assert not torch.equal(w1.detach(), ref_w1)
+
+
+def test_work_partition_stress_with_tiny_blocks(cuda, monkeypatch):
+    """Many small random graphs with the partition knobs turned down (item weight 64, column blocks
+    of 16, pieces >= 4), so that every cut / merge / tail path of plan.hip:build_items runs, in all
+    launch orders, for the full-wave and the sub-group kernels."""
+    gen = torch.Generator().manual_seed(123)
+    for trial in range(24):
+        monkeypatch.setenv("TGCN_ITEM_WEIGHT", "64")
+        monkeypatch.setenv("TGCN_COL_BLOCK", str([16, 7, 64, 0][trial % 4]))
+        monkeypatch.setenv("TGCN_MIN_PIECE", str([4, 1, 9][trial % 3]))
+        monkeypatch.setenv("TGCN_ITEM_ORDER", str([3, 4, 0, 1, 2][trial % 5]))
+        n = int(torch.randint(2, 700, (1,), generator=gen))
+        e = int(torch.randint(0, 9000, (1,), generator=gen))
+        g = synth.random_graph(n, e, seed=trial, self_loops=trial % 5, duplicates=(trial * 7) % 40)
+        ei, w = g.edge_index, g.edge_attr
+        if trial % 3 == 0 and n > 10:                       # add hubs: rows far longer than the item weight
+            hub = torch.randint(0, n, (3,), generator=gen)
+            src = torch.randint(0, n, (3, 400), generator=gen)
+            extra = torch.stack([src.flatten(), hub.repeat_interleave(400)])
+            ei = torch.cat([ei, extra, extra.flip(0)], 1)
+            w = torch.cat([w, torch.rand(2 * extra.shape[1], generator=gen) + 0.1])
+        plan = GraphPlan(ei.to(cuda), w.to(cuda), n, add_self_loops=trial % 4 != 1)
+        for F in (200, 64, 12, 3):
+            x = torch.randn(n, F, generator=gen)
+            b = torch.randn(F, generator=gen)
+            ref = oracle_spmm(ei, w, n, x, b, add_self_loops=trial % 4 != 1)
+            assert rel_err(plan.spmm(x.to(cuda), b.to(cuda)), ref) < TOL, (trial, F)
+            ref_t = oracle_spmm(ei, w, n, x, transpose=True, add_self_loops=trial % 4 != 1)
+            assert rel_err(plan.spmm(x.to(cuda), transpose=True), ref_t) < TOL, (trial, F, "T")
+        plan.close()
+
+
+def test_one_plan_on_two_streams_and_two_threads(cuda):
+    """include/tgcn.h: a plan is immutable, so concurrent SpMMs on different streams / host threads
+    may share it (each call brings its own workspace)."""
+    import threading
+    g = synth.word_doc_graph(30000, 600000, seed=4, device=cuda)
+    plan = GraphPlan(g.edge_index, g.edge_attr, 30000)
+    xs = [torch.randn(30000, 200, device=cuda) for _ in range(2)]
+    refs = [plan.spmm(x) for x in xs]
+    torch.cuda.synchronize()
+    outs = [None, None]
+
+    def work(i):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(5):
+                outs[i] = plan.spmm(xs[i])
+        s.synchronize()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
