@@ -84,3 +84,26 @@ def n_windows(X, n_vocab: int, n_documents: int, seq_len: int, window_size: int 
         return _query(lib, h, 1)
     finally:
         lib.tgcn_wwedges_destroy(h)
+
+
+def _sym_diag_idx(row: int, col: int, n: int) -> int:
+    """Packed upper triangle incl. the diagonal, row-major -- the layout of `sliding_window_tester`'s
+    result (graphbuilder.pyx:214-227)."""
+    if row < col:
+        row, col = col, row
+    return col * n + row - (col + 1) * col // 2
+
+
+def test_sym_matrix() -> int:
+    """The reference's self-check of the packed index (graphbuilder.pyx:277-296), on all 10 slots
+    (the reference compares only the first 6)."""
+    mat = [0.0] * 10                                   # 4 x 4
+    mat[_sym_diag_idx(1, 1, 4)] = 10
+    mat[_sym_diag_idx(1, 2, 4)] = 20
+    mat[_sym_diag_idx(2, 0, 4)] = 30
+    mat[_sym_diag_idx(3, 3, 4)] = 100
+    mat[_sym_diag_idx(2, 3, 4)] = 120
+    return int(mat == [0, 0, 30, 0, 10, 20, 0, 0, 120, 100])
+
+
+test_sym_matrix.__test__ = False                      # a library function, not a pytest case

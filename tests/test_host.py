@@ -108,3 +108,11 @@ def test_sharded_module_imports_without_a_process_group():
     g = synth.word_doc_graph(400, 3000, seed=2)
     p = sharded.Partition(g.edge_index, 400, 3, torch.arange(400) < g.n_vocab)
     assert p.n_local == p.hp + p.rp and p.hp * 3 >= g.n_vocab
+
+
+def test_reference_import_paths_exist():
+    # flat_amazon.py:13-14, test_cfunc.py:7 with `textgcn` -> `pytextgcn_amd`
+    from pytextgcn_amd import Text2GraphTransformer  # noqa: F401
+    from pytextgcn_amd.lib.models import GCN
+    from pytextgcn_amd.lib import sliding_window_tester, test_sym_matrix, compute_word_word_edges  # noqa: F401
+    assert GCN is pkg.GCN and test_sym_matrix() == 1
