@@ -23,6 +23,7 @@ namespace tgcn {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxSmall = 256;  // k, n <= 256
 
@@ -31,7 +32,7 @@ constexpr int kMaxSmall = 256;  // k, n <= 256
 // One wave per 32 rows, NT tiles of 32 columns each (npad = 32*NT).  TRANS_B selects how the small
 // operand is read from memory: B[k][n] (nn) or B[n][k] (nt).
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool TRANS_B, bool K8>
+template <int NT, bool TRANS_B, bool K8, int NQ>
 __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
@@ -77,10 +78,53 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
                 return v;
             }
         };
+        const float *bbase = lds + (4 * half) * npad + r;
+        if constexpr (NQ > 0) {
+            // k = 8 NQ known at compile time: the k-loop is fully unrolled, so the A pieces can sit in
+            // an 8-deep ring of INLINE-ASM loads with counted waits and no loop back edge between an
+            // issue and its use (hipcc copies loop-carried asm outputs, which would read registers
+            // whose load is still in flight).  hipcc itself waits vmcnt(0) on any prefetch it can
+            // see, leaving 8 MFMAs = 512 cycles of cover against ~3000 cycles of HBM latency; here
+            // seven pieces (56 MFMAs) stay in flight.  The wait takes the ring slot as an in/out
+            // operand so that no consumer can be scheduled above it.
+            f32x4 ring[8];
+#define TGCN_LDA(slot, q) \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[slot]) : "v"(arow + 8 * (q)) : "memory")
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < NQ) TGCN_LDA(j, j);
+            float bfr[2][4][NT];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bfr[0][s4][t] = bbase[s4 * npad + 32 * t];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+                    const float *bq = bbase + (8 * (q + 1)) * npad;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) bfr[(q + 1) & 1][s4][t] = bq[s4 * npad + 32 * t];
+                }
+                if (q + 7 < NQ)
+                    asm volatile("s_waitcnt vmcnt(7)" : "+v"(ring[q & 7])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[q & 7])::"memory");
+                const f32x4 a = ring[q & 7];
+                const float av[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bfr[q & 1][s4][t], acc[t], 0, 0, 0);
+                if (q + 8 < NQ) TGCN_LDA(q & 7, q + 8);
+            }
+#undef TGCN_LDA
+        } else {
         // B fragments of step group q: rows 8q + 4 half + s, columns r + 32 t; software pipeline:
         // three A pieces in flight, next group's B fragments read from LDS under the current MFMAs.
         // (A static 4-deep ring with the loop unrolled by 4 measured slower: 0.81 vs 0.73 ms.)
-        const float *bbase = lds + (4 * half) * npad + r;
         float bcur[4][NT], bnxt[4][NT];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
@@ -109,6 +153,7 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
             a0 = a1;
             a1 = a2;
             a2 = a3;
+        }
         }
         // C[(i&3) + 8*(i>>2) + 4*half][32 t + r]
 #pragma unroll
@@ -280,9 +325,9 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             n_cu = prop.multiProcessorCount;
     }
-#define TGCN_TALL_K(NT, K8)                                                                       \
+#define TGCN_TALL_K(NT, K8, NQ_)                                                                     \
     do {                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8>);           \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_>);      \
         TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                            static_cast<int>(lds_bytes)));                         \
         int per_cu = 1;                                                                           \
@@ -290,15 +335,26 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         per_cu = std::max(1, std::min(per_cu, 4));                                                \
         const int grid = static_cast<int>(                                                        \
             std::max<int64_t>(1, std::min<int64_t>((n_blocks + 3) / 4, int64_t(n_cu) * per_cu))); \
-        k_gemm_tall<NT, TRANS_B, K8><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n); \
+        k_gemm_tall<NT, TRANS_B, K8, NQ_><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n); \
     } while (0)
 #define TGCN_TALL(NT)                                                                             \
     do {                                                                                          \
         if (k % 8 == 0)                                                                           \
-            TGCN_TALL_K(NT, true);                                                                \
+            TGCN_TALL_K(NT, true, 0);                                                             \
         else                                                                                      \
-            TGCN_TALL_K(NT, false);                                                               \
+            TGCN_TALL_K(NT, false, 0);                                                            \
     } while (0)
+    // the two shapes of the GCN layers get fully unrolled k-loops (hidden width 200, class width 64)
+    if (!TRANS_B && k == 200 && nt == 2) {
+        TGCN_TALL_K(2, true, 25);
+        TGCN_HIP_CHECK(hipGetLastError());
+        return TGCN_OK;
+    }
+    if (TRANS_B && k == 64 && nt == 7) {
+        TGCN_TALL_K(7, true, 8);
+        TGCN_HIP_CHECK(hipGetLastError());
+        return TGCN_OK;
+    }
     switch (nt) {
         case 1: TGCN_TALL(1); break;
         case 2: TGCN_TALL(2); break;
