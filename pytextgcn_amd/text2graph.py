@@ -66,8 +66,18 @@ def _encode_input(X: List[str], n_jobs, vocabulary: Dict[str, int], verbose, n_d
     if verbose > 0:
         print("Tokenizing text and removing unwanted words...")
     sl = slice(None) if max_len is None else slice(max_len)
-    docs = [[vocabulary[t] for t in (x.lower() for x in _WORD.findall(doc)) if t in vocabulary][sl]
-            for doc in X]
+
+    def encode(chunk):
+        return [[vocabulary[t] for t in (x.lower() for x in _WORD.findall(doc)) if t in vocabulary][sl]
+                for doc in chunk]
+
+    if n_jobs is not None and n_jobs != 1 and len(X) >= 2000:
+        import joblib as jl                       # the reference tokenises with joblib too (:28,40)
+        step = max(500, len(X) // (8 * max(1, n_jobs if n_jobs > 0 else 8)))
+        parts = jl.Parallel(n_jobs=n_jobs)(jl.delayed(encode)(X[i:i + step]) for i in range(0, len(X), step))
+        docs = [d for part in parts for d in part]
+    else:
+        docs = encode(X)
     max_sent_len = max(map(len, docs)) if docs else 0
     if verbose > 1:
         print(f"Sequence length is {max_sent_len}")
