@@ -71,7 +71,7 @@ def _encode_input(X: List[str], n_jobs, vocabulary: Dict[str, int], verbose, n_d
         return [[vocabulary[t] for t in (x.lower() for x in _WORD.findall(doc)) if t in vocabulary][sl]
                 for doc in chunk]
 
-    if n_jobs is not None and n_jobs != 1 and len(X) >= 2000:
+    if n_jobs is not None and n_jobs != 1 and len(X) >= 50000:   # below that the pool start-up costs more
         import joblib as jl                       # the reference tokenises with joblib too (:28,40)
         step = max(500, len(X) // (8 * max(1, n_jobs if n_jobs > 0 else 8)))
         parts = jl.Parallel(n_jobs=n_jobs)(jl.delayed(encode)(X[i:i + step]) for i in range(0, len(X), step))
