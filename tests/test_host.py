@@ -116,3 +116,25 @@ def test_reference_import_paths_exist():
     from pytextgcn_amd.lib.models import GCN
     from pytextgcn_amd.lib import sliding_window_tester, test_sym_matrix, compute_word_word_edges  # noqa: F401
     assert GCN is pkg.GCN and test_sym_matrix() == 1
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01b_bench_c4_n1.json is a bench.py line measured on an MI355X; its shape is the
+    driver's contract (task statement) plus the `roofline` and `cpu_baseline` objects."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "r01b_bench_c4_n1.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    assert abs(d["value"] - 2 * 50_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "edges/s" and c["sample"]
