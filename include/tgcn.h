@@ -126,6 +126,14 @@ int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx,
               const float *bias, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
               tgcn_stream stream);
 
+/* tgcn_spmm_split -- tgcn_spmm whose gathered operand lives in two buffers: rows (= columns of the
+ * operator) [0, split) in X, rows [split, n_cols) in X2 (row r of X2 is column split + r).  No
+ * counterpart in the reference (single device); the 1-D partition keeps the all-gathered hub block
+ * and the rank's own rows apart and so avoids one copy per SpMM.  X2 = NULL is tgcn_spmm. */
+int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2,
+                    int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
+                    void *workspace, size_t workspace_bytes, tgcn_stream stream);
+
 /* tgcn_colsum -- replaces the autograd of `out += bias` (db = sum over rows of dOut).
  *   G [n_rows, F] fp32 stride ldg -> out [F]. */
 size_t tgcn_colsum_workspace_bytes(int64_t n_rows, int F);

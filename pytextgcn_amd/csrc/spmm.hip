@@ -18,6 +18,7 @@
 //   * row sums stay in registers; a finished row is written once, with the bias added.  Long rows
 //     write one partial per segment into the carry workspace and k_spmm_fix adds them in slot
 //     order (LDS across the 4 waves), so the result is bitwise reproducible.
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -77,7 +78,8 @@ template <int VEC, int U, int POLICY>
 __device__ __forceinline__ void spmm_item(
     const WorkItem it, const int lane, const int col0, const int F,
     const int32_t *__restrict__ rowptr, const int2 *__restrict__ cv, const float *__restrict__ X,
-    const int64_t ldx, const float *__restrict__ bias, float *__restrict__ Y, const int64_t ldy,
+    const int64_t ldx, const float *__restrict__ X2, const int64_t ldx2, const int split,
+    const float *__restrict__ bias, float *__restrict__ Y, const int64_t ldy,
     float *__restrict__ carry, const int64_t ldc) {
     using V = Vec<VEC>;
     using vec_t = typename V::type;
@@ -98,7 +100,10 @@ __device__ __forceinline__ void spmm_item(
     int row_end = segment ? nnz_end : readlane_i(rp_lane, 0);
 
     vec_t acc = V::zero();
+    // split operand: columns [0, split) live in X, columns [split, ...) in X2 (the sharded path keeps
+    // the gathered hub block and the rank's own rows in two buffers; split = INT_MAX otherwise)
     const float *xl = X + lc;
+    const float *xl2 = X2 + lc - int64_t(split) * ldx2;
 
     auto store_row = [&](float *dst, const vec_t &v) {
         if (!active) return;
@@ -142,7 +147,8 @@ __device__ __forceinline__ void spmm_item(
             for (int u = 0; u < U; ++u) {
                 const int c = readlane_i(mine.x, j0 + u);
                 v[u] = readlane_f(mine.y, j0 + u);
-                x[u] = *reinterpret_cast<const vec_t *>(xl + int64_t(c) * ldx);
+                const float *src = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
+                x[u] = *reinterpret_cast<const vec_t *>(src);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -173,15 +179,15 @@ __device__ __forceinline__ void spmm_item(
 template <int VEC, int U, int POLICY>
 __global__ __launch_bounds__(256) void k_spmm_gather(
     const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
-    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
-    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
-    int64_t ldc) {
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ X2, int64_t ldx2, int split, int F, const float *__restrict__ bias,
+    float *__restrict__ Y, int64_t ldy, float *__restrict__ carry, int64_t ldc) {
     const int lane = threadIdx.x & 63;
     const int item_id =
         __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (item_id >= n_items) return;
-    spmm_item<VEC, U, POLICY>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, bias,
-                              Y, ldy, carry, ldc);
+    spmm_item<VEC, U, POLICY>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, X2, ldx2,
+                              split, bias, Y, ldy, carry, ldc);
 }
 
 // Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row): the wave splits into
@@ -193,9 +199,9 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
 template <int G, int U>
 __global__ __launch_bounds__(256) void k_spmm_sub(
     const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
-    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx, int F,
-    const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, float *__restrict__ carry,
-    int64_t ldc) {
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ X2, int64_t ldx2, int split, int F, const float *__restrict__ bias,
+    float *__restrict__ Y, int64_t ldy, float *__restrict__ carry, int64_t ldc) {
     constexpr int S = 64 / G;
     const int lane = threadIdx.x & 63;
     const int item_id =
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
     float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias != nullptr) bvec = *reinterpret_cast<const float4 *>(bias + lc);
     const float *xl = X + lc;
+    const float *xl2 = X2 + lc - int64_t(split) * ldx2;
 
     // sum over entries start, start + stride, ... < end (per sub-group values)
     auto run = [&](int start, int stride, int end) -> float4 {
@@ -228,7 +235,8 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
                     const int c = __builtin_amdgcn_ds_bpermute(src, e.x);
                     v[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, e.y));
                     if (u0 + u >= G) v[u] = 0.f;
-                    x[u] = *reinterpret_cast<const float4 *>(xl + int64_t(c) * ldx);
+                    const float *xsrc = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
+                    x[u] = *reinterpret_cast<const float4 *>(xsrc);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -325,8 +333,8 @@ bool narrow_from_env() {
 }
 
 template <int VEC>
-int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
-               int64_t ldy, float *carry, hipStream_t stream) {
+int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
+               int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
     const int64_t ldc = round_up4(F);
     if (b.n_items > 0) {
@@ -334,15 +342,15 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
         if (VEC == 4 && F <= 128 && narrow_from_env()) {
             // narrow feature rows (the layer-2 width C): sub-group kernel
             if (F <= 64)
-                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F,
-                                                           bias, Y, ldy, carry, ldc);
+                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2,
+                                                           split, F, bias, Y, ldy, carry, ldc);
             else
-                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F,
-                                                           bias, Y, ldy, carry, ldc);
+                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2,
+                                                           split, F, bias, Y, ldy, carry, ldc);
         } else {
 #define TGCN_LAUNCH(UU, PP)                                                                      \
-    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, F, \
-                                                         bias, Y, ldy, carry, ldc)
+    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2, \
+                                                         split, F, bias, Y, ldy, carry, ldc)
             if constexpr (VEC == 4) {
                 switch (variant_from_env()) {
                     case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;   // plain loads / stores (for A/B runs)
@@ -365,13 +373,19 @@ int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, int F, const floa
 
 }  // namespace
 
-int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, int F, const float *bias, float *Y,
-                int64_t ldy, float *carry, hipStream_t stream) {
-    const uintptr_t align = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
-                            reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(carry);
-    const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (align % 16 == 0);
-    return vec4 ? launch_vec<4>(b, X, ldx, F, bias, Y, ldy, carry, stream)
-                : launch_vec<1>(b, X, ldx, F, bias, Y, ldy, carry, stream);
+int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
+                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
+    if (X2 == nullptr) {  // single operand
+        X2 = X;
+        ldx2 = ldx;
+        split = INT32_MAX;
+    }
+    const uintptr_t align = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) |
+                            reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias) |
+                            reinterpret_cast<uintptr_t>(carry);
+    const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldx2 % 4 == 0) && (ldy % 4 == 0) && (align % 16 == 0);
+    return vec4 ? launch_vec<4>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream)
+                : launch_vec<1>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream);
 }
 
 }  // namespace tgcn
@@ -387,9 +401,20 @@ size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F) {
 int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, int F,
               const float *bias, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
               tgcn_stream stream) {
+    return tgcn_spmm_split(plan, transpose, X, ldx, nullptr, 0, 0, F, bias, Y, ldy, workspace,
+                           workspace_bytes, stream);
+}
+
+int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2,
+                    int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
+                    void *workspace, size_t workspace_bytes, tgcn_stream stream) {
     using namespace tgcn;
     if (!plan || !X || !Y) {
         set_error("tgcn_spmm: NULL plan/X/Y");
+        return TGCN_E_INVALID;
+    }
+    if (X2 != nullptr && (ldx2 < F || split < 0 || split > INT32_MAX)) {
+        set_error("tgcn_spmm_split: need ldx2 >= F and 0 <= split < 2^31");
         return TGCN_E_INVALID;
     }
     if (F <= 0 || ldx < F || ldy < F) {
@@ -415,7 +440,8 @@ int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx,
     int cur = -1;
     TGCN_HIP_CHECK(hipGetDevice(&cur));
     if (cur != plan->device) TGCN_HIP_CHECK(hipSetDevice(plan->device));
-    const int st = launch_spmm(b, X, ldx, F, bias, Y, ldy, need ? static_cast<float *>(workspace) : nullptr,
+    const int st = launch_spmm(b, X, ldx, X2, ldx2, static_cast<int>(split), F, bias, Y, ldy,
+                               need ? static_cast<float *>(workspace) : nullptr,
                                static_cast<hipStream_t>(stream));
     if (cur != plan->device) (void)hipSetDevice(cur);
     return st;

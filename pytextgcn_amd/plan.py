@@ -143,14 +143,27 @@ class GraphPlan:
 
     # -- compute ----------------------------------------------------------------------------
     def spmm(self, x: Tensor, bias: Optional[Tensor] = None, transpose: bool = False,
-             out: Optional[Tensor] = None) -> Tensor:
-        """out[r] = sum_j M(^T)[row_begin + r, j] x[j] (+ bias); x is [num_nodes, F] fp32."""
+             out: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
+        """out[r] = sum_j M(^T)[row_begin + r, j] x[j] (+ bias); x is [num_nodes, F] fp32.
+        With `x2` the operand is split: columns [0, len(x)) read x, the remaining ones x2."""
         _require_cuda(x, "x")
         if x.dtype != torch.float32 or x.dim() != 2:
             raise TypeError(f"spmm operand must be a 2-D float32 tensor, got {x.dtype} {tuple(x.shape)}")
         need = self.n_cols_t if transpose else self.n_cols
-        if x.size(0) != need:
-            raise ValueError(f"operand has {x.size(0)} rows, the operator has {need} columns")
+        if x2 is not None and x.size(0) == 0:             # everything lives in the second buffer
+            x, x2 = x2, None
+        if x2 is not None and x2.size(0) == 0:
+            x2 = None
+        split = x.size(0)
+        if x2 is not None:
+            _require_cuda(x2, "x2")
+            if x2.dtype != torch.float32 or x2.dim() != 2 or x2.size(1) != x.size(1):
+                raise TypeError("x2 must be float32 with the same number of columns as x")
+            if x2.stride(1) != 1:
+                x2 = x2.contiguous()
+        if x.size(0) + (0 if x2 is None else x2.size(0)) != need:
+            raise ValueError(f"operand has {x.size(0) + (0 if x2 is None else x2.size(0))} rows, "
+                             f"the operator has {need} columns")
         n_out = self.n_rows_t if transpose else self.n_rows
         if x.stride(1) != 1:
             x = x.contiguous()
@@ -165,8 +178,9 @@ class GraphPlan:
             raise ValueError("`out` must be float32 [n_rows, F] with unit column stride")
         ws_bytes = self._lib.tgcn_spmm_workspace_bytes(self._h, int(transpose), F)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
-        _lib.check(self._lib.tgcn_spmm(
-            self._h, int(transpose), x.data_ptr(), x.stride(0), F,
+        _lib.check(self._lib.tgcn_spmm_split(
+            self._h, int(transpose), x.data_ptr(), x.stride(0),
+            x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, split, F,
             bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
             ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(x.device)))
         return out

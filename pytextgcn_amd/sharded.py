@@ -204,22 +204,22 @@ class ShardedGraph:
         F = x_local.size(1)
         key = (F, x_local.dtype)
         xbuf = self._xbuf.get(key)
-        if xbuf is None:
-            xbuf = torch.empty(W * hp + rp, F, dtype=x_local.dtype, device=x_local.device)
+        if xbuf is None:                       # gathered hub block only: the own rows are read in place
+            xbuf = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
             self._xbuf = {key: xbuf}
         if hp == 0:
             raise ValueError("a sharded graph needs at least one hub node per rank")
-        ag = dist.all_gather_into_tensor(xbuf[:W * hp], x_local[:hp], group=self.group, async_op=True)
+        ag = dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)
         rs = rs_out = None
         if A is not None:
-            xbuf[W * hp:].copy_(x_local[hp:])
             partial = A.spmm(x_local[hp:])                       # overlaps the all-gather
             ag.wait()
             rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
             rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
         else:
             ag.wait()
-        y = B.spmm(xbuf, bias)                                   # overlaps the reduce-scatter
+        # split operand: hub columns from the gathered block, own regular columns straight from x_local
+        y = B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)   # overlaps the reduce-scatter
         if rs is not None:
             rs.wait()
             y[:hp] += rs_out

@@ -21,7 +21,9 @@ class _OracleOp:
         self.n_rows, self.n_cols = n_rows, n_cols
         self.csr = csr_oracle.coo_to_csr(row, col, val, n_rows)
 
-    def spmm(self, x, bias=None):
+    def spmm(self, x, bias=None, x2=None):
+        if x2 is not None:
+            x = torch.cat([x, x2])
         assert x.shape[0] == self.n_cols
         return csr_oracle.csr_spmm(*self.csr, x.contiguous(), bias)
 

@@ -678,3 +678,20 @@ def test_one_plan_on_two_streams_and_two_threads(cuda):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
+
+
+@pytest.mark.parametrize("F", [200, 64, 6])
+def test_split_operand_spmm(cuda, F):
+    """tgcn_spmm_split: columns [0, split) from one buffer, the rest from another (sharded path)."""
+    g = synth.random_graph(900, 12000, seed=31, self_loops=4, duplicates=9)
+    ei, w = g.edge_index.to(cuda), g.edge_attr.to(cuda)
+    plan = GraphPlan(ei, w, 900)
+    x = torch.randn(900, F, device=cuda)
+    b = torch.randn(F, device=cuda)
+    ref = plan.spmm(x, b)
+    for split in (0, 1, 333, 899):
+        a, c = x[:split].clone(), torch.randn(1200, F, device=cuda)
+        c[77:77 + 900 - split] = x[split:]
+        assert torch.equal(plan.spmm(a, b, x2=c[77:77 + 900 - split]), ref), split
+    with pytest.raises(ValueError):
+        plan.spmm(x[:10], b, x2=x[:5])
