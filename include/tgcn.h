@@ -59,7 +59,8 @@ const char *tgcn_last_error(void);
  *   src, src_stride       edge_index[0] (int64) and its element stride: the reference passes the
  *   dst, dst_stride       non-contiguous view `coo.T` (text2graph.py:192), so strides are honoured
  *   w                     edge_attr (fp32, contiguous) or NULL for all-ones
- *   add_self_loops        GCNConv(add_self_loops=...) -- the reference always passes True
+ *   add_self_loops        GCNConv(add_self_loops=...) -- the reference always passes True; the value
+ *                         is also the weight of an added loop: 1 -> 1.0, 2 -> 2.0 (improved=True)
  *   normalize             GCNConv(normalize=...)      -- the reference keeps the default True; as in
  *                         PyG, loops are added inside gcn_norm, i.e. only when normalize != 0
  *   row_begin, row_end    rows [row_begin,row_end) of M and of M^T that this plan will produce

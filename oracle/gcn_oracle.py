@@ -67,13 +67,14 @@ def add_remaining_self_loops(edge_index: Tensor, edge_weight: Optional[Tensor], 
 # PyG 1.6.3 torch_geometric/nn/conv/gcn_conv.py: gcn_norm (dense edge_index branch)
 # --------------------------------------------------------------------------------------
 def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-             add_self_loops: bool = True, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
+             add_self_loops: bool = True, dtype=torch.float32, improved: bool = False) -> Tuple[Tensor, Tensor]:
     """deg is the weighted IN-degree at the target (`edge_index[1]`), loops included;
     `w_hat = deg^-1/2[row] * w * deg^-1/2[col]` with inf -> 0."""
     if edge_weight is None:
         edge_weight = torch.ones((edge_index.size(1),), dtype=dtype, device=edge_index.device)
     if add_self_loops:
-        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, num_nodes)
+        fill_value = 2.0 if improved else 1.0                     # gcn_conv.py: `fill_value = 2. if improved else 1.`
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes)
     row, col = edge_index[0], edge_index[1]
     deg = torch.zeros(num_nodes, dtype=edge_weight.dtype, device=edge_weight.device)
     deg.index_add_(0, col, edge_weight)                      # scatter_add(edge_weight, col)

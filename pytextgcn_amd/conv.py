@@ -122,8 +122,6 @@ class GCNConv(nn.Module):
                  cached: bool = False, add_self_loops: bool = True, normalize: bool = True,
                  bias: bool = True, **kwargs):
         super().__init__()
-        if improved:
-            raise NotImplementedError("improved=True (loop weight 2) is never used by PyTextGCN")
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.improved = improved
@@ -144,7 +142,8 @@ class GCNConv(nn.Module):
                 self.bias.zero_()
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
-        plan = plan_for(edge_index, edge_weight, x.size(0), self.add_self_loops, self.normalize)
+        loops = (2 if self.improved else 1) if self.add_self_loops else 0     # fill weight of added loops
+        plan = plan_for(edge_index, edge_weight, x.size(0), loops, self.normalize)
         if x.is_sparse:
             if x.size(1) != self.in_channels:
                 raise ValueError(f"x has {x.size(1)} features, the layer expects {self.in_channels}")

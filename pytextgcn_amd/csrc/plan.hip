@@ -83,7 +83,7 @@ __global__ void k_scan_edges(int64_t E, const int64_t *__restrict__ src, int64_t
 __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t ss,
                             const int64_t *__restrict__ dst, int64_t ds,
                             const float *__restrict__ w, int64_t N, int64_t n_cols, int add_loops,
-                            const unsigned long long *__restrict__ loop_eid,
+                            float loop_fill, const unsigned long long *__restrict__ loop_eid,
                             uint64_t *__restrict__ keys, float *__restrict__ vals) {
     const int64_t total = E + (add_loops ? N : 0);
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
@@ -100,7 +100,7 @@ __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t 
             const int64_t n = i - E;
             const unsigned long long le = loop_eid[n];
             keys[i] = (static_cast<uint64_t>(n) << 32) | static_cast<uint64_t>(n);
-            vals[i] = le ? (w ? w[le - 1] : 1.0f) : 1.0f;
+            vals[i] = le ? (w ? w[le - 1] : 1.0f) : loop_fill;
         }
     }
 }
@@ -536,8 +536,8 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
 
     if (total > 0) {
         k_make_keys<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
-            E, src, ss, dst, ds, w, n_rows, n_cols, add_loops, loop_eid.as<unsigned long long>(),
-            keys_a.as<uint64_t>(), vals_a.as<float>());
+            E, src, ss, dst, ds, w, n_rows, n_cols, add_loops, static_cast<float>(add_loops),
+            loop_eid.as<unsigned long long>(), keys_a.as<uint64_t>(), vals_a.as<float>());
         TGCN_HIP_CHECK(hipGetLastError());
     }
     unsigned node_bits = 1;
@@ -687,8 +687,9 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64
     plan->row_begin = row_begin;
     plan->row_end = row_end;
     // PyG adds the loops inside gcn_norm, so GCNConv(normalize=False) never sees them
+    // add_self_loops doubles as the fill weight: 1 -> 1.0, 2 -> 2.0 (GCNConv(improved=True))
     const int st = plan_create_impl(n_nodes, n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
-                                    add_self_loops != 0 && normalize != 0, normalize != 0, 1,
+                                    normalize != 0 ? std::max(0, std::min(add_self_loops, 2)) : 0, normalize != 0, 1,
                                     row_begin, row_end, static_cast<hipStream_t>(stream), *plan);
     if (st != TGCN_OK) {
         free_block(plan->fwd);

@@ -32,7 +32,7 @@ class GraphPlan:
     as CSR with interleaved (col, val) pairs, plus M^T unless the operator is symmetric."""
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                 add_self_loops: bool = True, normalize: bool = True,
+                 add_self_loops=True, normalize: bool = True,
                  row_range: Optional[Tuple[int, int]] = None):
         lib = _lib.load()
         _require_cuda(edge_index, "edge_index")

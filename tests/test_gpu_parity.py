@@ -695,3 +695,15 @@ def test_split_operand_spmm(cuda, F):
         assert torch.equal(plan.spmm(a, b, x2=c[77:77 + 900 - split]), ref), split
     with pytest.raises(ValueError):
         plan.spmm(x[:10], b, x2=x[:5])
+
+
+def test_improved_gcnconv_fill_weight_two(cuda):
+    """GCNConv(improved=True): added self loops weigh 2.0 (PyG gcn_norm `fill_value`); never used by
+    the reference, supported for signature completeness."""
+    g = synth.random_graph(300, 2500, seed=41, self_loops=5, duplicates=3)
+    ei, w = g.edge_index, g.edge_attr
+    conv = pkg.GCNConv(12, 9, improved=True).to(cuda)
+    x = torch.randn(300, 12)
+    nei, nw = O.gcn_norm(ei, w, 300, improved=True)
+    ref = O.propagate(nei, x @ conv.weight.detach().cpu(), nw, 300) + conv.bias.detach().cpu()
+    assert rel_err(conv(x.to(cuda), ei.to(cuda), w.to(cuda)), ref) < TOL
