@@ -5,11 +5,11 @@ and `models`): `models.GCN(in, out, n_hidden_gcn=..., dropout=...)(graph)` runs 
 layers as hand-written HIP kernels (libtgcn.so, include/tgcn.h) on an AMD Instinct MI355X.
 """
 from . import functional, models, optim
-from .conv import GCNConv
+from .conv import GCNConv, enable_activation_reuse
 from .data import Data
 from .models import GCN
 from .plan import GraphPlan, clear_plan_cache, colsum, plan_for
 from .text2graph import Text2GraphTransformer
 
 __all__ = ["Text2GraphTransformer", "models", "functional", "optim", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
-           "clear_plan_cache"]
+           "clear_plan_cache", "enable_activation_reuse"]

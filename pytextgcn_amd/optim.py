@@ -50,4 +50,7 @@ class Adam(Optimizer):
                     p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     vmax.data_ptr() if vmax is not None else None, p.numel(), group["lr"], b1, b2,
                     group["eps"], group["weight_decay"], st["step"], _stream_ptr(p.device)))
+                # the kernel wrote through raw pointers: tell autograd (and the activation cache of
+                # pytextgcn_amd.conv) that the parameter changed, as an in-place torch op would
+                torch.autograd.graph.increment_version(p)
         return loss

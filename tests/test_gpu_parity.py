@@ -707,3 +707,34 @@ def test_improved_gcnconv_fill_weight_two(cuda):
     nei, nw = O.gcn_norm(ei, w, 300, improved=True)
     ref = O.propagate(nei, x @ conv.weight.detach().cpu(), nw, 300) + conv.bias.detach().cpu()
     assert rel_err(conv(x.to(cuda), ei.to(cuda), w.to(cuda)), ref) < TOL
+
+
+def test_activation_reuse_is_bitwise_neutral_and_invalidates(cuda):
+    """enable_activation_reuse(): the eval forward's layer-1 output serves the next training forward
+    (same W1, b1); any parameter update -- torch's or the fused Adam's -- must invalidate it."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    N, C = 4000, 5
+    g = synth.word_doc_graph(N, 50000, seed=23, n_classes=C, device=cuda)
+    for Opt in (torch.optim.Adam, pkg.optim.Adam):
+        runs = []
+        for reuse in (False, True):
+            pkg.enable_activation_reuse(reuse)
+            torch.manual_seed(5)
+            m = pkg.GCN(N, C, n_hidden_gcn=32, dropout=0.5).to(cuda)
+            opt = Opt(m.parameters(), lr=0.05, amsgrad=True)
+            torch.manual_seed(6)                               # same dropout masks in both runs
+            hist = []
+            for _ in range(4):
+                m.train()
+                loss = masked_cross_entropy(m(g), g.y, g.train_mask)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                m.eval()
+                with torch.no_grad():
+                    hist.append((loss.item(), m(g).clone()))
+            runs.append((hist, m.layers[0].weight.detach().clone()))
+        pkg.enable_activation_reuse(False)
+        for (la, za), (lb, zb) in zip(runs[0][0], runs[1][0]):
+            assert la == lb and torch.equal(za, zb)
+        assert torch.equal(runs[0][1], runs[1][1])
