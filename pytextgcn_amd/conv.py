@@ -186,13 +186,13 @@ class GCNConv(nn.Module):
                 if _REUSE:
                     key = _reuse_key(plan, self.weight, self.bias)
                     hit = getattr(self, "_reuse_cache", None)
-                    if hit is not None and hit[0] == key:
+                    if hit is not None and hit[0] == key and hit[2] is plan:   # `is`: an id() can be recycled
                         if torch.is_grad_enabled() and (self.weight.requires_grad or
                                                         (self.bias is not None and self.bias.requires_grad)):
                             return _PropagateCached.apply(plan, self.weight, self.bias, hit[1])
                         return hit[1].detach()
                     out = propagate(plan, self.weight, self.bias)
-                    self._reuse_cache = (key, out.detach())
+                    self._reuse_cache = (key, out.detach(), plan)
                     return out
                 xw = self.weight
             else:
