@@ -204,5 +204,12 @@ class GCNConv(nn.Module):
             xw = dense.xw(x, self.weight)     # fp32 MFMA kernels for tall-skinny shapes
         return propagate(plan, xw, self.bias)
 
+    def __getstate__(self):
+        # th.save(gcn, ...) pickles the whole module (flat_amazon.py:128): cached activations and the
+        # plan they point to (a ctypes handle) stay behind
+        state = self.__dict__.copy()
+        state.pop("_reuse_cache", None)
+        return state
+
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

@@ -735,6 +735,8 @@ def test_activation_reuse_is_bitwise_neutral_and_invalidates(cuda):
                     hist.append((loss.item(), m(g).clone()))
             runs.append((hist, m.layers[0].weight.detach().clone()))
         pkg.enable_activation_reuse(False)
+        import pickle
+        pickle.loads(pickle.dumps(m))                          # th.save(gcn) with a populated cache
         for (la, za), (lb, zb) in zip(runs[0][0], runs[1][0]):
             assert la == lb and torch.equal(za, zb)
         assert torch.equal(runs[0][1], runs[1][1])
