@@ -98,9 +98,12 @@ def measured_traffic(config, n_gpus):
 def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False):
     """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
     bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
-    fused=False: the reference's loop body verbatim (torch CrossEntropyLoss on mask-indexed rows,
-    torch.optim.Adam) around pytextgcn_amd.GCN;  fused=True: the same steps with
-    pytextgcn_amd.functional.masked_cross_entropy and pytextgcn_amd.optim.Adam."""
+    fused=False: the reference's loop body with its own operators (torch CrossEntropyLoss on
+    mask-indexed rows, torch.optim.Adam) around pytextgcn_amd.GCN;  fused=True: the same steps with
+    pytextgcn_amd.functional.masked_cross_entropy and pytextgcn_amd.optim.Adam.
+    "Metric transfer" (BASELINE.md section 2): the arg-max of the masked logits is taken on the
+    device and the PREDICTIONS go to the host; the reference ships the masked logits themselves
+    (flat_amazon.py:111-112) and runs numpy / sklearn on them, which is host work outside this path."""
     import pytextgcn_amd as pkg
     from pytextgcn_amd.functional import masked_cross_entropy
     N = g.y.numel()
