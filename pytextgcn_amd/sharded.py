@@ -155,6 +155,15 @@ class ShardedGraph:
         self.plan = self.ops[0][1]            # the larger local operator (for reporting)
         self._xbuf = {}
 
+    @classmethod
+    def from_data(cls, g, group=None, **kw) -> "ShardedGraph":
+        """From the graph object Text2GraphTransformer returns (text2graph.py:192-193): the word nodes
+        [0, g.n_vocab) become the replicated hubs, the documents stay with their owners."""
+        n = g.x.shape[0] if getattr(g, "x", None) is not None else int(g.edge_index.max()) + 1
+        n_vocab = int(getattr(g, "n_vocab", 0) or 0)
+        hubs = torch.arange(n, device=g.edge_index.device) < n_vocab if n_vocab > 0 else None
+        return cls(g.edge_index, g.edge_attr, n, group=group, hubs=hubs, **kw)
+
     # ---- construction ---------------------------------------------------------------------------
     def _local_ops(self, t: Tensor, s: Tensor, w: Tensor):
         """A_r and B_r from the global triplets M[t, s] = w."""

@@ -75,7 +75,11 @@ def check(kind, device="cpu"):
     N = g.y.numel()
     if device != "cpu":
         return check_hip(kind, g, hubs, N, torch.device(device))
-    sg = sharded.ShardedGraph(g.edge_index, g.edge_attr, N, hubs=hubs, engine=OracleEngine())
+    if kind == "wordoc":
+        sg = sharded.ShardedGraph.from_data(g, engine=OracleEngine())          # hubs = words, from n_vocab
+        assert torch.equal(sg.part.hub_mask, hubs)
+    else:
+        sg = sharded.ShardedGraph(g.edge_index, g.edge_attr, N, hubs=hubs, engine=OracleEngine())
     # every node is owned exactly once
     own = [sg.part.owned(q) for q in range(world)]
     allids = torch.cat([o[o >= 0] for o in own])
