@@ -201,6 +201,14 @@ int tgcn_wwedges_export(const tgcn_wwedges *we, int32_t *coo /* [n_edges][2] */,
                         tgcn_stream stream);
 int tgcn_wwedges_destroy(tgcn_wwedges *we);
 
+/* tgcn_adam_step_capturable -- the same update with the step count on the DEVICE (torch's
+ * `capturable=True`): `step_dev` (int64) is incremented by the call and `scalars_dev` (2 floats of
+ * scratch) receives the step-dependent factors, so a captured HIP graph can be replayed per step. */
+int tgcn_adam_step_capturable(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                              float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                              double eps, double weight_decay, int64_t *step_dev, float *scalars_dev,
+                              tgcn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

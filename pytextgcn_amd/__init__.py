@@ -4,12 +4,12 @@ Mirrors the reference's public surface (textgcn/__init__.py:1-4 exports `Text2Gr
 and `models`): `models.GCN(in, out, n_hidden_gcn=..., dropout=...)(graph)` runs the two GCNConv
 layers as hand-written HIP kernels (libtgcn.so, include/tgcn.h) on an AMD Instinct MI355X.
 """
-from . import functional, models, optim
+from . import functional, models, optim, train
 from .conv import GCNConv, enable_activation_reuse
 from .data import Data
 from .models import GCN
 from .plan import GraphPlan, clear_plan_cache, colsum, plan_for
 from .text2graph import Text2GraphTransformer
 
-__all__ = ["Text2GraphTransformer", "models", "functional", "optim", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
+__all__ = ["Text2GraphTransformer", "models", "functional", "optim", "train", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
            "clear_plan_cache", "enable_activation_reuse"]

@@ -56,6 +56,9 @@ SIGNATURES = {
     "tgcn_wwedges_destroy": (c_int, [c_void_p]),
     "tgcn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                c_double, c_double, c_double, c_double, c_int64, c_void_p]),
+    "tgcn_adam_step_capturable": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                                          c_double, c_double, c_double, c_double, c_void_p, c_void_p,
+                                          c_void_p]),
 }
 
 _lib = None

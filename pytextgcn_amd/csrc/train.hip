@@ -87,12 +87,29 @@ __device__ __forceinline__ float lerp_torch(float a, float b, float w) {
 // torch/optim/adam.py (_single_tensor_adam), op for op:
 //   g += wd * p;  m.lerp_(g, 1-b1);  v = b2*v + (1-b2)*g*g;  vmax = max(vmax, v)   [amsgrad]
 //   denom = sqrt(vmax or v) / sqrt(1 - b2^t) + eps;  p -= (lr / (1 - b1^t)) * m / denom
+// Capturable form: the step count lives on the device (torch's `capturable=True`), so that one
+// captured HIP graph can be replayed for every training step.  One thread advances the counter and
+// derives the two step-dependent scalars in double, exactly as the host path does.
+__global__ void k_adam_scalars(int64_t *step, double lr, double b1, double b2, float *scalars) {
+    const int64_t s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow(b1, static_cast<double>(s));
+    const double bc2 = 1.0 - pow(b2, static_cast<double>(s));
+    scalars[0] = static_cast<float>(lr / bc1);
+    scalars[1] = static_cast<float>(1.0 / sqrt(bc2));
+}
+
 template <bool AMSGRAD>
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
                                               float *__restrict__ m, float *__restrict__ v,
                                               float *__restrict__ vmax, int64_t n, float w1 /* 1-b1 */,
                                               float b2, float w2 /* 1-b2 */, float eps, float wd,
-                                              float step_size, float inv_bc2_sqrt) {
+                                              float step_size, float inv_bc2_sqrt,
+                                              const float *__restrict__ dev_scalars) {
+    if (dev_scalars != nullptr) {
+        step_size = dev_scalars[0];
+        inv_bc2_sqrt = dev_scalars[1];
+    }
     const int64_t stride = int64_t(gridDim.x) * blockDim.x * 4;
     for (int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -182,9 +199,34 @@ int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classe
     return TGCN_OK;
 }
 
+static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                     float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int64_t step, int64_t *step_dev, float *scalars_dev,
+                     tgcn_stream stream);
+
 int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, tgcn_stream stream) {
+    return adam_impl(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                     step, nullptr, nullptr, stream);
+}
+
+int tgcn_adam_step_capturable(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                              float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                              double eps, double weight_decay, int64_t *step_dev, float *scalars_dev,
+                              tgcn_stream stream) {
+    if (!step_dev || !scalars_dev) {
+        tgcn::set_error("tgcn_adam_step_capturable: step_dev / scalars_dev must be device pointers");
+        return TGCN_E_INVALID;
+    }
+    return adam_impl(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                     1, step_dev, scalars_dev, stream);
+}
+
+static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                     float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int64_t step, int64_t *step_dev, float *scalars_dev,
+                     tgcn_stream stream) {
     using namespace tgcn;
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) {
         set_error("tgcn_adam_step: bad argument (n=%lld step=%lld)", (long long)n, (long long)step);
@@ -208,12 +250,16 @@ int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
     const float inv_bc2_sqrt = static_cast<float>(1.0 / std::sqrt(bc2));
     const int grid = static_cast<int>(std::min<int64_t>(8192, (n / 4 + 255) / 256 + 1));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (step_dev != nullptr) {
+        k_adam_scalars<<<1, 1, 0, s>>>(step_dev, lr, beta1, beta2, scalars_dev);
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
     if (max_exp_avg_sq)
         k_adam<true><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, w1, b2f, w2,
-                                          epsf, wdf, step_size, inv_bc2_sqrt);
+                                          epsf, wdf, step_size, inv_bc2_sqrt, scalars_dev);
     else
         k_adam<false><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, nullptr, n, w1, b2f, w2, epsf,
-                                           wdf, step_size, inv_bc2_sqrt);
+                                           wdf, step_size, inv_bc2_sqrt, scalars_dev);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }

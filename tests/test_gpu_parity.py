@@ -740,3 +740,40 @@ def test_activation_reuse_is_bitwise_neutral_and_invalidates(cuda):
         for (la, za), (lb, zb) in zip(runs[0][0], runs[1][0]):
             assert la == lb and torch.equal(za, zb)
         assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_graphed_training_matches_eager_training(cuda):
+    """pytextgcn_amd.train: one HIP-graph replay per optimisation step / eval forward gives the same
+    losses, logits and weights as the eager loop (dropout off: identical arithmetic)."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.train import GraphedEval, GraphedTrainStep
+    N, C = 3000, 6
+    g = synth.word_doc_graph(N, 40000, seed=27, n_classes=C, device=cuda)
+    torch.manual_seed(9)
+    eager = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    graphed = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    graphed.load_state_dict(eager.state_dict())
+    o_e = pkg.optim.Adam(eager.parameters(), lr=0.05, amsgrad=True)
+    o_g = pkg.optim.Adam(graphed.parameters(), lr=0.05, amsgrad=True, capturable=True)
+    with pytest.raises(ValueError):
+        GraphedTrainStep(eager, g, o_e, g.train_mask)
+    step = GraphedTrainStep(graphed, g, o_g, g.train_mask, warmup=2)
+    ev = GraphedEval(graphed, g)
+    eager.train()
+    losses_e = []
+    for _ in range(6):
+        loss = masked_cross_entropy(eager(g), g.y, g.train_mask)
+        o_e.zero_grad(set_to_none=True)
+        loss.backward()
+        o_e.step()
+        losses_e.append(loss.item())
+    losses_g = [step().item() for _ in range(4)]                 # steps 3..6 (2 were the warm-up)
+    assert step.steps == 6 and int(o_g.state[graphed.layers[0].weight]["step"]) == 6
+    for a, b in zip(losses_e[2:], losses_g):
+        assert abs(a - b) < 1e-5 * abs(a) + 1e-7
+    for pe, pg in zip(eager.parameters(), graphed.parameters()):
+        assert rel_err(pg, pe) < 1e-4
+    eager.eval()
+    with torch.no_grad():
+        assert rel_err(ev(), eager(g)) < 1e-4
+    assert graphed.training                                       # GraphedEval restores the mode
