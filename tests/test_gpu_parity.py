@@ -777,3 +777,26 @@ def test_graphed_training_matches_eager_training(cuda):
     with torch.no_grad():
         assert rel_err(ev(), eager(g)) < 1e-4
     assert graphed.training                                       # GraphedEval restores the mode
+
+
+def test_three_layer_gcn_and_general_sparse_features(cuda):
+    """n_gcn = 3 (input -> h -> h -> classes, models.py:11-15) and a sparse feature matrix that is NOT
+    the identity (falls back to torch.sparse.mm for X @ W1)."""
+    N, Fin, C = 1500, 90, 7
+    g = synth.word_doc_graph(N, 18000, seed=33, n_classes=C)
+    gen = torch.Generator().manual_seed(3)
+    dense_x = torch.randn(N, Fin, generator=gen) * (torch.rand(N, Fin, generator=gen) < 0.1)
+    g.x = dense_x.to_sparse().coalesce()
+    torch.manual_seed(2)
+    ref = O.GCNOracle(Fin, C, n_gcn=3, n_hidden_gcn=48, dropout=0.0)
+    mine = pkg.GCN(Fin, C, n_gcn=3, n_hidden_gcn=48, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    lo_r, lo_m = ref(g), mine(gd)
+    assert rel_err(lo_m, lo_r) < TOL
+    crit = torch.nn.CrossEntropyLoss()
+    crit(lo_r[g.train_mask], g.y[g.train_mask]).backward()
+    crit(lo_m[gd.train_mask], gd.y[gd.train_mask]).backward()
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad, pr.grad) < 5 * TOL, k
