@@ -95,7 +95,7 @@ def measured_traffic(config, n_gpus):
         return None
 
 
-def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False):
+def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
     """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
     bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
     fused=False: the reference's loop body with its own operators (torch CrossEntropyLoss on
@@ -108,6 +108,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False):
     from pytextgcn_amd.functional import masked_cross_entropy
     N = g.y.numel()
     pkg.enable_activation_reuse(reuse)
+    pkg.enable_linear_collapse(collapse)
     model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
     Opt = pkg.optim.Adam if fused else torch.optim.Adam
     opt = Opt(model.parameters(), lr=0.05, amsgrad=True)
@@ -140,6 +141,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False):
             times.append((time.perf_counter() - t0) * 1e3)
     del model, opt
     pkg.enable_activation_reuse(False)
+    pkg.enable_linear_collapse(False)
     return sorted(times)[len(times) // 2]
 
 
@@ -312,7 +314,7 @@ def main():
     launch_bytes = 0.5 * (bytes_fwd + bytes_bwd)
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
 
-    epoch_ms = epoch_ms_fused = epoch_ms_reuse = None
+    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
@@ -321,6 +323,7 @@ def main():
         epoch_ms = epoch_time_ms(g, F, C, fused=False)
         epoch_ms_fused = epoch_time_ms(g, F, C, fused=True)
         epoch_ms_reuse = epoch_time_ms(g, F, C, fused=True, reuse=True)
+        epoch_ms_collapse = epoch_time_ms(g, F, C, fused=True, collapse=True)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -351,6 +354,9 @@ def main():
             # NOT part of the metric: the fused loop with pytextgcn_amd.enable_activation_reuse(), which
             # hands the eval forward's layer-1 output (same W1, b1) to the next training forward
             "epoch_ms_fused_with_activation_reuse": epoch_ms_reuse,
+            # NOT part of the metric either: pytextgcn_amd.enable_linear_collapse() evaluates the eval forward of
+            # the activation-free network (models.py:22) as two propagations at the class width
+            "epoch_ms_fused_with_collapsed_eval": epoch_ms_collapse,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac)

@@ -176,33 +176,36 @@ class GCNConv(nn.Module):
                 self.bias.zero_()
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
+        plan = self.plan(x, edge_index, edge_weight)
+        if _REUSE and x.is_sparse and x.size(1) == self.in_channels and is_sparse_identity(x):
+            # layer 1 of TextGCN: one-hot features, X @ W1 is W1; keep M @ W1 + b1 while W1, b1 are unchanged
+            key = _reuse_key(plan, self.weight, self.bias)
+            hit = getattr(self, "_reuse_cache", None)
+            if hit is not None and hit[0] == key and hit[2] is plan:   # `is`: an id() can be recycled
+                if torch.is_grad_enabled() and (self.weight.requires_grad or
+                                                (self.bias is not None and self.bias.requires_grad)):
+                    return _PropagateCached.apply(plan, self.weight, self.bias, hit[1])
+                return hit[1].detach()
+            out = propagate(plan, self.weight, self.bias)
+            self._reuse_cache = (key, out.detach(), plan)
+            return out
+        return propagate(plan, self.features_times(x, self.weight), self.bias)
+
+    def plan(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> GraphPlan:
         loops = (2 if self.improved else 1) if self.add_self_loops else 0     # fill weight of added loops
-        plan = plan_for(edge_index, edge_weight, x.size(0), loops, self.normalize)
-        if x.is_sparse:
-            if x.size(1) != self.in_channels:
-                raise ValueError(f"x has {x.size(1)} features, the layer expects {self.in_channels}")
-            # layer 1 of TextGCN: one-hot features, so X @ W1 is W1 (and dW1 = dXW, no GEMM)
-            if is_sparse_identity(x):
-                if _REUSE:
-                    key = _reuse_key(plan, self.weight, self.bias)
-                    hit = getattr(self, "_reuse_cache", None)
-                    if hit is not None and hit[0] == key and hit[2] is plan:   # `is`: an id() can be recycled
-                        if torch.is_grad_enabled() and (self.weight.requires_grad or
-                                                        (self.bias is not None and self.bias.requires_grad)):
-                            return _PropagateCached.apply(plan, self.weight, self.bias, hit[1])
-                        return hit[1].detach()
-                    out = propagate(plan, self.weight, self.bias)
-                    self._reuse_cache = (key, out.detach(), plan)
-                    return out
-                xw = self.weight
-            else:
-                h = split_identity_block(x)
-                n = x.size(0)
-                xw = (self.weight[:n] + torch.sparse.mm(h, self.weight[n:]) if h is not None
-                      else torch.sparse.mm(x, self.weight))
-        else:
-            xw = dense.xw(x, self.weight)     # fp32 MFMA kernels for tall-skinny shapes
-        return propagate(plan, xw, self.bias)
+        return plan_for(edge_index, edge_weight, x.size(0), loops, self.normalize)
+
+    def features_times(self, x: Tensor, w: Tensor) -> Tensor:
+        """X @ w for the feature formats of text2graph.py:226-246 (`w` has `in_channels` rows)."""
+        if not x.is_sparse:
+            return dense.xw(x, w)             # fp32 MFMA kernels for tall-skinny shapes
+        if x.size(1) != self.in_channels:
+            raise ValueError(f"x has {x.size(1)} features, the layer expects {self.in_channels}")
+        if is_sparse_identity(x):
+            return w
+        h = split_identity_block(x)
+        n = x.size(0)
+        return w[:n] + torch.sparse.mm(h, w[n:]) if h is not None else torch.sparse.mm(x, w)
 
     def __getstate__(self):
         # th.save(gcn, ...) pickles the whole module (flat_amazon.py:128): cached activations and the

@@ -800,3 +800,41 @@ def test_three_layer_gcn_and_general_sparse_features(cuda):
     crit(lo_m[gd.train_mask], gd.y[gd.train_mask]).backward()
     for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
         assert rel_err(pm.grad, pr.grad) < 5 * TOL, k
+
+
+@pytest.mark.parametrize("n_gcn,features", [(2, "identity"), (3, "identity"), (2, "hier"), (2, "dense")])
+def test_linear_collapse_eval_forward(cuda, n_gcn, features):
+    """Opt-in collapsed eval forward (pytextgcn_amd.enable_linear_collapse): the activation-free network of
+    models.py:17-25 evaluated as L propagations at the output width.  Not bitwise (different
+    association) -- held to the same 1e-5 bar against the oracle; the training forward is untouched."""
+    N, C, H = 3000, 9, 56
+    g = synth.word_doc_graph(N, 40000, seed=21, n_classes=C)
+    if features == "hier":
+        hier = torch.zeros(N, 5)
+        hier[g.n_vocab:, :] = torch.nn.functional.one_hot(torch.randint(0, 5, (N - g.n_vocab,)), 5).float()
+        g.x = torch.cat([torch.eye(N), hier], dim=1).to_sparse().coalesce()
+    elif features == "dense":
+        g.x = torch.randn(N, 40)
+    Fin = g.x.shape[1]
+    torch.manual_seed(4)
+    ref = O.GCNOracle(Fin, C, n_gcn=n_gcn, n_hidden_gcn=H, dropout=0.5).eval()
+    with torch.no_grad():
+        for layer in ref.layers:
+            layer.bias.uniform_(-0.5, 0.5)         # exercise the bias chain b_i W_{i+1}...W_L
+    mine = pkg.GCN(Fin, C, n_gcn=n_gcn, n_hidden_gcn=H, dropout=0.5)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float().eval()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    with torch.no_grad():
+        want = ref(g)
+        plain = mine(gd)
+        pkg.enable_linear_collapse(True)
+        try:
+            fast = mine(gd)
+            mine.train()
+            assert mine(gd).shape == fast.shape        # training mode with dropout: regular path
+        finally:
+            pkg.enable_linear_collapse(False)
+    assert rel_err(plain, want) < TOL
+    assert rel_err(fast, want) < TOL
+    assert not torch.equal(fast, plain) or n_gcn == 1
