@@ -55,7 +55,7 @@ def main():
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
                      f"{float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                      f"{float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
-    for kname in ("k_spmm_gather", "k_spmm_fix"):
+    for kname in ("k_spmm_gather", "k_spmm_hot", "k_spmm_fix"):
         tr = [r for r in trace(stats_dir) if kname in r["Kernel_Name"]]
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
         lines += ["", f"`{kname}` dispatches: {len(dur)}; durations (us), in launch order:", "",

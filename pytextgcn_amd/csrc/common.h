@@ -61,7 +61,23 @@ struct CsrBlock {
     int32_t n_fix = 0;
     int32_t n_segments = 0;
     size_t bytes = 0;
+    // Dense hot block (plan.hip: build_items; spmm.hip: k_spmm_hot).  When n_hot > 0 the lists above
+    // leave the hot rows out (their fix entries point at the partial sums of k_spmm_hot, carry rows
+    // [hot_slot_base + k * hot_parts, ...)) and the *_all lists hold the complete partition for the
+    // scalar fallback kernel.
+    int32_t n_hot = 0;
+    int32_t hot_parts = 0;      // workgroups of k_spmm_hot = partial sums per hot row
+    int32_t hot_cpw = 0;        // columns per wave of k_spmm_hot (even)
+    int32_t hot_slot_base = 0;
+    float *hot_vals = nullptr;  // [hot_parts * 8 * hot_cpw][kHotRows], zero padded
+    WorkItem *items_all = nullptr;
+    int32_t n_items_all = 0;
+    FixEntry *fix_all = nullptr;
+    int32_t n_fix_all = 0;
+    int32_t n_segments_all = 0;
 };
+
+constexpr int kHotRows = 32;    // one MFMA M-tile
 
 void free_block(CsrBlock &b);
 

@@ -258,12 +258,31 @@ __global__ void k_block_cuts(const int32_t *__restrict__ long_rows, int n_long,
     pos[idx] = lo;
 }
 
+// Dense value block of the hot rows: vd[c * 32 + k] = sum of the entries (hot_rows[k], c).  One thread
+// per entry; duplicates of a column are adjacent (columns are sorted within a row) and are summed, in
+// storage order, by the thread that owns the first of them.
+__global__ void k_hot_fill(const int32_t *__restrict__ hot_rows, const int32_t *__restrict__ rowptr,
+                           const int2 *__restrict__ cv, float *__restrict__ vd) {
+    const int k = blockIdx.y;
+    const int32_t r = hot_rows[k];
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    for (int32_t j = b + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
+        const int c = cv[j].x;
+        if (j > b && cv[j - 1].x == c) continue;
+        float s = __int_as_float(cv[j].y);
+        for (int32_t q = j + 1; q < e && cv[q].x == c; ++q) s += __int_as_float(cv[q].y);
+        vd[int64_t(c) * kHotRows + k] = s;
+    }
+}
+
 // Tuning knobs (tools/sweep_spmm.py); the defaults are the measured best on config c4.
 struct Knobs {
     int col_block;  // columns per block for long-row cuts; 0 = no column cuts
     int min_piece;  // merge adjacent column blocks of a row until a piece has this many entries
     int order;      // 0 = row order, 1 = segments first, 2 = row blocks first, 3 = interleaved,
                     // 4 = interleaved in XCD-affine queues (column block j -> XCD j % 8)
+    int hot_rows;   // 0 = never build the dense hot block
+    double hot_ratio;  // build it when the 32 longest rows hold >= hot_ratio * n_cols entries
 };
 
 Knobs knobs_from_env() {
@@ -275,6 +294,9 @@ Knobs knobs_from_env() {
     k.col_block = geti("TGCN_COL_BLOCK", 8192);
     k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 64));
     k.order = geti("TGCN_ITEM_ORDER", 3);
+    k.hot_rows = geti("TGCN_HOT_ROWS", 1);
+    const char *hr = std::getenv("TGCN_HOT_RATIO");
+    k.hot_ratio = hr ? std::atof(hr) : 2.0;
     return k;
 }
 
@@ -292,6 +314,9 @@ void free_block(CsrBlock &b) {
     if (b.cv) (void)hipFree(b.cv);
     if (b.items) (void)hipFree(b.items);
     if (b.fix) (void)hipFree(b.fix);
+    if (b.items_all) (void)hipFree(b.items_all);
+    if (b.fix_all) (void)hipFree(b.fix_all);
+    if (b.hot_vals) (void)hipFree(b.hot_vals);
     b = CsrBlock{};
 }
 
@@ -364,135 +389,225 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         TGCN_HIP_CHECK(hipStreamSynchronize(stream));
     }
 
-    // pass 2: segments
+    // The dense hot block (spmm.hip: k_spmm_hot).  The K longest rows of a word-document operator are
+    // nearly dense (the most frequent words occur in most documents): gathering X[col] once per
+    // entry re-reads every document row once per hot word.  When the K = 32 longest rows together
+    // hold >= hot_ratio * n_cols entries they are taken out of the gather partition and computed as
+    // a dense [32 x n_cols] x [n_cols x F] product that streams X exactly once (fp32 MFMA).
+    std::vector<int32_t> hot_of_long(static_cast<size_t>(n_long), -1);   // long-row index -> hot index
+    std::vector<int32_t> hot_rows;
+    if (kn.hot_rows > 0 && n_long > 0 && b.n_cols >= 4096) {
+        std::vector<int32_t> idx(static_cast<size_t>(n_long));
+        for (int32_t i = 0; i < n_long; ++i) idx[i] = i;
+        const size_t k = std::min<size_t>(kHotRows, idx.size());
+        auto deg = [&](int32_t i) { return rp[long_rows[i] + 1] - rp[long_rows[i]]; };
+        std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), [&](int32_t x, int32_t y) {
+            return deg(x) != deg(y) ? deg(x) > deg(y) : x < y;
+        });
+        int64_t sum = 0;
+        for (size_t q = 0; q < k; ++q) sum += deg(idx[q]);
+        if (static_cast<double>(sum) >= kn.hot_ratio * static_cast<double>(b.n_cols)) {
+            for (size_t q = 0; q < k; ++q) {
+                hot_of_long[idx[q]] = static_cast<int32_t>(q);
+                hot_rows.push_back(long_rows[idx[q]]);
+            }
+        }
+    }
+    const int32_t n_hot = static_cast<int32_t>(hot_rows.size());
+    if (n_hot > 0) {
+        // every wave of the hot kernel streams `cpw` consecutive columns, 8 waves per
+        // workgroup, at most 256 workgroups; the value block is padded to the full grid with zeros
+        // cpw is a multiple of 8 = one load stage of the kernel (4 column pairs), so a stage never
+        // reaches into the next wave's columns
+        int64_t cpw = (b.n_cols + 256 * 8 - 1) / (256 * 8);
+        cpw = std::max<int64_t>(64, (cpw + 7) & ~int64_t(7));
+        const int64_t per_wg = cpw * 8;
+        b.hot_parts = static_cast<int32_t>((b.n_cols + per_wg - 1) / per_wg);
+        b.hot_cpw = static_cast<int32_t>(cpw);
+        b.n_hot = n_hot;
+        DevBuf d_vals, d_hot;
+        const size_t vbytes = sizeof(float) * static_cast<size_t>(b.hot_parts) * per_wg * kHotRows;
+        TGCN_CHECK(d_vals.alloc(vbytes));
+        TGCN_CHECK(d_hot.alloc(sizeof(int32_t) * kHotRows));
+        TGCN_HIP_CHECK(hipMemsetAsync(d_vals.p, 0, vbytes, stream));
+        TGCN_HIP_CHECK(hipMemcpyAsync(d_hot.p, hot_rows.data(), sizeof(int32_t) * n_hot,
+                                      hipMemcpyHostToDevice, stream));
+        int32_t max_deg = 0;
+        for (int32_t r : hot_rows) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
+        dim3 grid(static_cast<unsigned>(std::min<int64_t>((max_deg + kThreads - 1) / kThreads, 4096)), n_hot);
+        k_hot_fill<<<grid, kThreads, 0, stream>>>(d_hot.as<int32_t>(), b.rowptr, b.cv, d_vals.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        TGCN_HIP_CHECK(hipStreamSynchronize(stream));   // hot_rows (host) is read by the copy above
+        b.bytes += d_vals.bytes;
+        b.hot_vals = static_cast<float *>(d_vals.release());
+    }
+
+    // pass 2: segments of the long rows, launch order, fix list.  Built once for the complete operator
+    // and, when there is a hot block, once more without the hot rows (the list the float4 kernels use
+    // next to k_spmm_hot; the complete list then only serves the scalar fallback kernel).
     struct Seg {
         WorkItem it;
         int32_t key;
     };
-    std::vector<Seg> segs;
-    std::vector<FixEntry> fix;
-    fix.reserve(n_long);
-    int64_t slots = 0;
-    auto emit_piece = [&](int32_t r, int32_t nb, int32_t ne, int32_t key) {
-        const int32_t d = ne - nb;
-        const int32_t nseg = (d + T - 1) / T;
-        const int32_t seglen = (d + nseg - 1) / nseg;
-        for (int32_t s = 0; s < nseg; ++s) {
-            const int32_t sb = std::min(nb + s * seglen, ne);
-            const int32_t se = std::min(sb + seglen, ne);
-            segs.push_back({{r, -static_cast<int32_t>(slots) - 1, sb, se}, key});
-            ++slots;
+    struct Lists {
+        std::vector<WorkItem> items;
+        std::vector<FixEntry> fix;
+        int64_t slots = 0;
+        int32_t hot_slot_base = 0;
+    };
+    bool overflow = false;
+    auto make_lists = [&](bool skip_hot, Lists &out) {
+        std::vector<Seg> segs;
+        std::vector<FixEntry> &fix = out.fix;
+        fix.reserve(n_long);
+        int64_t slots = 0;
+        auto emit_piece = [&](int32_t r, int32_t nb, int32_t ne, int32_t key) {
+            const int32_t d = ne - nb;
+            const int32_t nseg = (d + T - 1) / T;
+            const int32_t seglen = (d + nseg - 1) / nseg;
+            for (int32_t s = 0; s < nseg; ++s) {
+                const int32_t sb = std::min(nb + s * seglen, ne);
+                const int32_t se = std::min(sb + seglen, ne);
+                segs.push_back({{r, -static_cast<int32_t>(slots) - 1, sb, se}, key});
+                ++slots;
+            }
+        };
+        for (int32_t i = 0; i < n_long; ++i) {
+            if (skip_hot && hot_of_long[i] >= 0) continue;
+            const int32_t r = long_rows[i];
+            const int64_t slot_begin = slots;
+            if (n_cb > 0) {
+                const int32_t *c = cuts.data() + static_cast<size_t>(i) * (n_cb + 1);
+                int32_t j0 = 0;
+                for (int32_t j = 1; j <= n_cb; ++j) {
+                    const bool last = j == n_cb;
+                    if (c[j] - c[j0] >= kn.min_piece || (last && c[j] > c[j0])) {
+                        // a short tail joins the previous piece instead of becoming a tiny one
+                        if (last && c[j] - c[j0] < kn.min_piece && !segs.empty() && segs.back().it.row_begin == r &&
+                            slots > slot_begin && (segs.back().it.nnz_end - segs.back().it.nnz_begin) + (c[j] - c[j0]) <= T) {
+                            segs.back().it.nnz_end = c[j];
+                        } else {
+                            emit_piece(r, c[j0], c[j], j0);
+                        }
+                        j0 = j;
+                    }
+                }
+            } else {
+                emit_piece(r, rp[r], rp[r + 1], 0);
+            }
+            fix.push_back({r, static_cast<int32_t>(slot_begin), static_cast<int32_t>(slots - slot_begin), 0});
+        }
+        if (skip_hot) {
+            // hot row k: one partial per workgroup of k_spmm_hot, carry rows [base + k P, base + (k+1) P)
+            out.hot_slot_base = static_cast<int32_t>(slots);
+            for (int32_t k = 0; k < n_hot; ++k)
+                fix.push_back({hot_rows[k], static_cast<int32_t>(slots + int64_t(k) * b.hot_parts), b.hot_parts, 0});
+            slots += int64_t(n_hot) * b.hot_parts;
+        }
+        if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) overflow = true;
+        out.slots = slots;
+        if (kn.order != 0)
+            std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.key < y.key; });
+
+        // launch order
+        std::vector<WorkItem> &items = out.items;
+        items.reserve(blocks.size() + segs.size() + 64);
+        if (kn.order == 4) {
+            // XCD-affine queues.  Workgroups are dealt round-robin over the 8 XCDs (workgroup w runs on
+            // XCD w % 8; observed placement, used for speed only) and a workgroup holds 4 items, so the
+            // item at launch position p lands on XCD (p / 4) % 8.  All segments of column block j go to
+            // queue j % 8: a slice of X is then pulled through the fabric by ONE XCD's L2 and re-used
+            // there by every long row, instead of being fetched once per XCD.  Row blocks fill the
+            // queues up to equal length; short queues are padded with empty items to keep alignment.
+            constexpr int kXcd = 8, kGroup = 4;
+            std::vector<std::vector<WorkItem>> q(kXcd);
+            std::vector<std::vector<WorkItem>> qseg(kXcd);
+            for (const Seg &sg : segs) qseg[sg.key % kXcd].push_back(sg.it);
+            const size_t total = segs.size() + blocks.size();
+            const size_t per_q = (total + kXcd - 1) / kXcd;
+            size_t bi = 0;
+            for (int x = 0; x < kXcd; ++x) {
+                const size_t ns = qseg[x].size();
+                const size_t nb = ns >= per_q ? 0 : std::min(per_q - ns, blocks.size() - bi);
+                // spread this queue's row blocks evenly between its segments
+                size_t si = 0, bj = 0;
+                while (si < ns || bj < nb) {
+                    if (bj >= nb || (si < ns && si * nb <= bj * ns))
+                        q[x].push_back(qseg[x][si++]);
+                    else
+                        q[x].push_back(blocks[bi + bj++]);
+                }
+                bi += nb;
+            }
+            for (int x = 0; bi < blocks.size(); x = (x + 1) % kXcd) q[x].push_back(blocks[bi++]);
+            size_t longest = 0;
+            for (int x = 0; x < kXcd; ++x) longest = std::max(longest, q[x].size());
+            const WorkItem empty = {0, 0, 0, 0};
+            for (size_t pos = 0; pos < longest; pos += kGroup)
+                for (int x = 0; x < kXcd; ++x)
+                    for (size_t k = pos; k < pos + kGroup; ++k) {
+                        if (k < q[x].size())
+                            items.push_back(q[x][k]);
+                        else if (pos + kGroup < longest || x < kXcd - 1)
+                            items.push_back(empty);
+                    }
+            while (!items.empty() && items.back().nnz_begin == items.back().nnz_end &&
+                   items.back().row_begin == items.back().row_end)
+                items.pop_back();
+        } else if (kn.order == 3) {
+            size_t si = 0, bi = 0;
+            const size_t ns = segs.size(), nb = blocks.size();
+            while (si < ns || bi < nb) {
+                if (bi >= nb || (si < ns && si * nb <= bi * ns))
+                    items.push_back(segs[si++].it);
+                else
+                    items.push_back(blocks[bi++]);
+            }
+        } else if (kn.order == 2) {
+            items = blocks;
+            for (const Seg &sg : segs) items.push_back(sg.it);
+        } else {
+            for (const Seg &sg : segs) items.push_back(sg.it);
+            items.insert(items.end(), blocks.begin(), blocks.end());
         }
     };
-    for (int32_t i = 0; i < n_long; ++i) {
-        const int32_t r = long_rows[i];
-        const int64_t slot_begin = slots;
-        if (n_cb > 0) {
-            const int32_t *c = cuts.data() + static_cast<size_t>(i) * (n_cb + 1);
-            int32_t j0 = 0;
-            for (int32_t j = 1; j <= n_cb; ++j) {
-                const bool last = j == n_cb;
-                if (c[j] - c[j0] >= kn.min_piece || (last && c[j] > c[j0])) {
-                    // a short tail joins the previous piece instead of becoming a tiny one
-                    if (last && c[j] - c[j0] < kn.min_piece && !segs.empty() && segs.back().it.row_begin == r &&
-                        slots > slot_begin && (segs.back().it.nnz_end - segs.back().it.nnz_begin) + (c[j] - c[j0]) <= T) {
-                        segs.back().it.nnz_end = c[j];
-                    } else {
-                        emit_piece(r, c[j0], c[j], j0);
-                    }
-                    j0 = j;
-                }
-            }
-        } else {
-            emit_piece(r, rp[r], rp[r + 1], 0);
-        }
-        fix.push_back({r, static_cast<int32_t>(slot_begin), static_cast<int32_t>(slots - slot_begin), 0});
+
+    auto upload = [&](const Lists &l, WorkItem *&d_items_out, int32_t &n_items, FixEntry *&d_fix_out,
+                      int32_t &n_fix, int32_t &n_slots) -> int {
+        n_items = static_cast<int32_t>(l.items.size());
+        n_fix = static_cast<int32_t>(l.fix.size());
+        n_slots = static_cast<int32_t>(l.slots);
+        DevBuf d_items, d_fix;
+        TGCN_CHECK(d_items.alloc(sizeof(WorkItem) * l.items.size()));
+        TGCN_CHECK(d_fix.alloc(sizeof(FixEntry) * l.fix.size()));
+        if (!l.items.empty())
+            TGCN_HIP_CHECK(hipMemcpyAsync(d_items.p, l.items.data(), sizeof(WorkItem) * l.items.size(),
+                                          hipMemcpyHostToDevice, stream));
+        if (!l.fix.empty())
+            TGCN_HIP_CHECK(hipMemcpyAsync(d_fix.p, l.fix.data(), sizeof(FixEntry) * l.fix.size(),
+                                          hipMemcpyHostToDevice, stream));
+        TGCN_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors die on return
+        b.bytes += d_items.bytes + d_fix.bytes;
+        d_items_out = static_cast<WorkItem *>(d_items.release());
+        d_fix_out = static_cast<FixEntry *>(d_fix.release());
+        return TGCN_OK;
+    };
+
+    Lists main_lists;
+    make_lists(n_hot > 0, main_lists);
+    if (!overflow) {
+        b.hot_slot_base = main_lists.hot_slot_base;
+        TGCN_CHECK(upload(main_lists, b.items, b.n_items, b.fix, b.n_fix, b.n_segments));
     }
-    if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) {
+    if (n_hot > 0 && !overflow) {
+        Lists all;
+        make_lists(false, all);
+        if (!overflow) TGCN_CHECK(upload(all, b.items_all, b.n_items_all, b.fix_all, b.n_fix_all, b.n_segments_all));
+    }
+    if (overflow) {
         set_error("work partition exceeds int32 limits");
         return TGCN_E_RANGE;
     }
-    if (kn.order != 0)
-        std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.key < y.key; });
-
-    // launch order
-    std::vector<WorkItem> items;
-    items.reserve(blocks.size() + segs.size() + 64);
-    if (kn.order == 4) {
-        // XCD-affine queues.  Workgroups are dealt round-robin over the 8 XCDs (workgroup w runs on
-        // XCD w % 8; observed placement, used for speed only) and a workgroup holds 4 items, so the
-        // item at launch position p lands on XCD (p / 4) % 8.  All segments of column block j go to
-        // queue j % 8: a slice of X is then pulled through the fabric by ONE XCD's L2 and re-used
-        // there by every long row, instead of being fetched once per XCD.  Row blocks fill the
-        // queues up to equal length; short queues are padded with empty items to keep alignment.
-        constexpr int kXcd = 8, kGroup = 4;
-        std::vector<std::vector<WorkItem>> q(kXcd);
-        std::vector<std::vector<WorkItem>> qseg(kXcd);
-        for (const Seg &sg : segs) qseg[sg.key % kXcd].push_back(sg.it);
-        const size_t total = segs.size() + blocks.size();
-        const size_t per_q = (total + kXcd - 1) / kXcd;
-        size_t bi = 0;
-        for (int x = 0; x < kXcd; ++x) {
-            const size_t ns = qseg[x].size();
-            const size_t nb = ns >= per_q ? 0 : std::min(per_q - ns, blocks.size() - bi);
-            // spread this queue's row blocks evenly between its segments
-            size_t si = 0, bj = 0;
-            while (si < ns || bj < nb) {
-                if (bj >= nb || (si < ns && si * nb <= bj * ns))
-                    q[x].push_back(qseg[x][si++]);
-                else
-                    q[x].push_back(blocks[bi + bj++]);
-            }
-            bi += nb;
-        }
-        for (int x = 0; bi < blocks.size(); x = (x + 1) % kXcd) q[x].push_back(blocks[bi++]);
-        size_t longest = 0;
-        for (int x = 0; x < kXcd; ++x) longest = std::max(longest, q[x].size());
-        const WorkItem empty = {0, 0, 0, 0};
-        for (size_t pos = 0; pos < longest; pos += kGroup)
-            for (int x = 0; x < kXcd; ++x)
-                for (size_t k = pos; k < pos + kGroup; ++k) {
-                    if (k < q[x].size())
-                        items.push_back(q[x][k]);
-                    else if (pos + kGroup < longest || x < kXcd - 1)
-                        items.push_back(empty);
-                }
-        while (!items.empty() && items.back().nnz_begin == items.back().nnz_end &&
-               items.back().row_begin == items.back().row_end)
-            items.pop_back();
-    } else if (kn.order == 3) {
-        size_t si = 0, bi = 0;
-        const size_t ns = segs.size(), nb = blocks.size();
-        while (si < ns || bi < nb) {
-            if (bi >= nb || (si < ns && si * nb <= bi * ns))
-                items.push_back(segs[si++].it);
-            else
-                items.push_back(blocks[bi++]);
-        }
-    } else if (kn.order == 2) {
-        items = blocks;
-        for (const Seg &sg : segs) items.push_back(sg.it);
-    } else {
-        for (const Seg &sg : segs) items.push_back(sg.it);
-        items.insert(items.end(), blocks.begin(), blocks.end());
-    }
-
-    b.n_items = static_cast<int32_t>(items.size());
-    b.n_fix = static_cast<int32_t>(fix.size());
-    b.n_segments = static_cast<int32_t>(slots);
-    DevBuf d_items, d_fix;
-    TGCN_CHECK(d_items.alloc(sizeof(WorkItem) * items.size()));
-    TGCN_CHECK(d_fix.alloc(sizeof(FixEntry) * fix.size()));
-    if (!items.empty())
-        TGCN_HIP_CHECK(hipMemcpyAsync(d_items.p, items.data(), sizeof(WorkItem) * items.size(),
-                                      hipMemcpyHostToDevice, stream));
-    if (!fix.empty())
-        TGCN_HIP_CHECK(hipMemcpyAsync(d_fix.p, fix.data(), sizeof(FixEntry) * fix.size(),
-                                      hipMemcpyHostToDevice, stream));
-    TGCN_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors die on return
-    b.bytes += d_items.bytes + d_fix.bytes;
-    b.items = static_cast<WorkItem *>(d_items.release());
-    b.fix = static_cast<FixEntry *>(d_fix.release());
     return TGCN_OK;
 }
 
@@ -784,6 +899,8 @@ int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out) {
         case TGCN_Q_ROW_BEGIN: *out = plan->row_begin; break;
         case TGCN_Q_HAS_TRANSPOSE: *out = (plan->has_transpose || plan->symmetric) ? 1 : 0; break;
         case TGCN_Q_N_ROWS_T: *out = t.n_rows; break;
+        case TGCN_Q_HOT_ROWS: *out = f.n_hot; break;
+        case TGCN_Q_HOT_ROWS_T: *out = t.n_hot; break;
         default:
             set_error("tgcn_plan_query: unknown selector %d", what);
             return TGCN_E_INVALID;

@@ -18,6 +18,7 @@
 //   * row sums stay in registers; a finished row is written once, with the bias added.  Long rows
 //     write one partial per segment into the carry workspace and k_spmm_fix adds them in slot
 //     order (LDS across the 4 waves), so the result is bitwise reproducible.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -274,6 +275,97 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
     }
 }
 
+// Dense hot block.  part[k][:] = sum over the columns c of this workgroup of vd[c][k] * X[c][:] for the
+// 32 hot rows k (plan.hip: build_items), as v_mfma_f32_32x32x2_f32 products: per step a wave takes two
+// consecutive columns c, c+1 -- the A fragment is 64 consecutive floats of vd (hot index = lane % 32,
+// column = lane / 32), the B fragments are 32-float pieces of the two operand rows -- and accumulates
+// NT tiles of 32 output columns.  X is read exactly once, in order (8 waves x `cpw` consecutive
+// columns per workgroup).  The 8 partial tiles of a workgroup are added in wave order through LDS and
+// written as ONE carry row per hot row; k_spmm_fix then adds the workgroups' rows in order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kHotWaves = 8;
+
+template <int NT>
+__global__ __launch_bounds__(64 * kHotWaves) void k_spmm_hot(
+    const float *__restrict__ vd, int64_t n_cols, int cpw, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ X2, int64_t ldx2, int split, int F, float *__restrict__ carry, int64_t ldc,
+    int slot_base, int n_parts, int n_hot) {
+    __shared__ float red[kHotWaves][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int col0 = blockIdx.y * (32 * NT);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // feature columns past F are clamped to a valid address and NOT zeroed: they only feed result
+    // columns >= F of the padded tile, which are never written
+    int xoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xoff[t] = min(col0 + 32 * t + c, F - 1);
+    const int64_t c_begin = (int64_t(blockIdx.x) * kHotWaves + wave) * cpw;   // vd is padded to the grid
+    const float *pv = vd + (c_begin + half) * kHotRows + c;
+    const int64_t last = n_cols - 1;
+    constexpr int UR = 4;                      // column pairs per stage, two stages in flight
+    float a[2][UR], x[2][UR][NT];
+    auto load_stage = [&](int buf, int64_t cc) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int64_t col = cc + 2 * u + half;
+            const int64_t cl = min(col, last);                 // padded tail: a valid row, weight 0 in vd
+            a[buf][u] = pv[(cc - c_begin + 2 * u) * kHotRows];
+            const float *row = cl < split ? X + cl * ldx : X2 + (cl - split) * ldx2;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float v = row[xoff[t]];
+                x[buf][u][t] = col <= last ? v : 0.f;          // 0 * garbage must stay 0
+            }
+        }
+    };
+    auto mfma_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u], x[buf][u][t], acc[t], 0, 0, 0);
+    };
+    // columns of this wave that exist: [c_begin, min(c_begin + cpw, n_cols)), walked in stages of 2 UR
+    const int64_t c_stop = min(c_begin + cpw, n_cols);
+    const int64_t n_stage = c_stop > c_begin ? (c_stop - c_begin + 2 * UR - 1) / (2 * UR) : 0;
+    // cpw is a multiple of 2 UR, so a stage stays inside this wave's columns; past n_cols it reads the
+    // zero padding of vd (allocated up to the grid size) and clamped operand rows
+    if (n_stage > 0) load_stage(0, c_begin);
+    for (int64_t st = 0; st < n_stage; st += 2) {
+        if (st + 1 < n_stage) load_stage(1, c_begin + (st + 1) * 2 * UR);
+        mfma_stage(0);
+        if (st + 1 < n_stage) {
+            if (st + 2 < n_stage) load_stage(0, c_begin + (st + 2) * 2 * UR);
+            mfma_stage(1);
+        }
+    }
+    // workgroup reduction, tile by tile, in wave order
+    const int part = blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[t][i];
+        __syncthreads();
+        const int col = col0 + 32 * t + c;
+#pragma unroll
+        for (int q = 0; q < 16 / kHotWaves; ++q) {
+            const int i = wave * (16 / kHotWaves) + q;
+            float sum = red[0][i][lane];
+#pragma unroll
+            for (int w = 1; w < kHotWaves; ++w) sum += red[w][i][lane];
+            const int k = (i & 3) + 8 * (i >> 2) + 4 * half;   // hot row of accumulator register i
+            if (k < n_hot && col < F)
+                carry[(int64_t(slot_base) + int64_t(k) * n_parts + part) * ldc + col] = sum;
+        }
+    }
+}
+
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
 template <int VEC>
@@ -332,24 +424,59 @@ bool narrow_from_env() {
     return on;
 }
 
+template <int NT>
+void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
+                float *carry, int64_t ldc, hipStream_t stream) {
+    dim3 grid(b.hot_parts, (F + 32 * NT - 1) / (32 * NT));
+    k_spmm_hot<NT><<<grid, 64 * kHotWaves, 0, stream>>>(b.hot_vals, b.n_cols, b.hot_cpw, X, ldx, X2, ldx2, split, F,
+                                                       carry, ldc, b.hot_slot_base, b.hot_parts, b.n_hot);
+}
+
 template <int VEC>
-int launch_vec(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
+int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
     const int64_t ldc = round_up4(F);
+    // With a dense hot block the float4 kernels run on the partition without the hot rows, next to
+    // k_spmm_hot; the scalar kernel (unaligned operands, F % 4 != 0) uses the complete partition.
+    struct View {
+        const WorkItem *items;
+        int32_t n_items;
+        const FixEntry *fix;
+        int32_t n_fix;
+    };
+    const bool all = VEC == 1 && blk.n_hot > 0;
+    const View b = all ? View{blk.items_all, blk.n_items_all, blk.fix_all, blk.n_fix_all}
+                       : View{blk.items, blk.n_items, blk.fix, blk.n_fix};
+    const int32_t *rowptr = blk.rowptr;
+    const int2 *cv = blk.cv;
+    if (VEC == 4 && blk.n_hot > 0) {
+        const int nt = std::min(8, (F + 31) / 32);   // 32-column MFMA tiles per wave (8 = 256 columns)
+        switch (nt) {
+            case 1: launch_hot<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 2: launch_hot<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 3: launch_hot<3>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 4: launch_hot<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 5: launch_hot<5>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 6: launch_hot<6>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            case 7: launch_hot<7>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+            default: launch_hot<8>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
+        }
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
         if (VEC == 4 && F <= 128 && narrow_from_env()) {
             // narrow feature rows (the layer-2 width C): sub-group kernel
             if (F <= 64)
-                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2,
+                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2,
                                                            split, F, bias, Y, ldy, carry, ldc);
             else
-                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2,
+                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2,
                                                            split, F, bias, Y, ldy, carry, ldc);
         } else {
 #define TGCN_LAUNCH(UU, PP)                                                                      \
-    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, b.rowptr, b.cv, X, ldx, X2, ldx2, \
+    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, \
                                                          split, F, bias, Y, ldy, carry, ldc)
             if constexpr (VEC == 4) {
                 switch (variant_from_env()) {
@@ -395,7 +522,8 @@ extern "C" {
 size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F) {
     if (!plan || F <= 0) return 0;
     const tgcn::CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
-    return sizeof(float) * static_cast<size_t>(b.n_segments) * static_cast<size_t>(tgcn::round_up4(F));
+    const size_t slots = static_cast<size_t>(std::max(b.n_segments, b.n_segments_all));
+    return sizeof(float) * slots * static_cast<size_t>(tgcn::round_up4(F));
 }
 
 int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, int F,

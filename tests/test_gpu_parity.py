@@ -9,7 +9,7 @@ import torch
 
 from oracle import csr_oracle, gcn_oracle as O
 import pytextgcn_amd as pkg
-from pytextgcn_amd import synth
+from pytextgcn_amd import _lib, synth
 from pytextgcn_amd.plan import GraphPlan, colsum
 
 pytestmark = pytest.mark.gpu
@@ -838,3 +838,75 @@ def test_linear_collapse_eval_forward(cuda, n_gcn, features):
     assert rel_err(plain, want) < TOL
     assert rel_err(fast, want) < TOL
     assert not torch.equal(fast, plain) or n_gcn == 1
+
+
+def _hub_graph(n, n_hubs, gen, dup=False):
+    """n nodes of which the first n_hubs are hubs connected to a large random share of the others
+    (both directions, asymmetric weights), plus a sparse random background."""
+    srcs, dsts = [], []
+    for h in range(n_hubs):
+        share = 0.9 / (1 + h * 0.35)
+        others = torch.nonzero(torch.rand(n, generator=gen) < share).flatten()
+        others = others[others != h]
+        srcs += [others, torch.full_like(others, h)]
+        dsts += [torch.full_like(others, h), others]
+    bg = torch.randint(0, n, (2, 4 * n), generator=gen)
+    srcs.append(bg[0]); dsts.append(bg[1])
+    ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
+    if dup:                                              # duplicate entries inside the hot rows
+        ei = torch.cat([ei, ei[:, :5000], ei[:, :700]], 1)
+    w = torch.rand(ei.shape[1], generator=gen) + 0.05
+    return ei, w
+
+
+@pytest.mark.parametrize("n,n_hubs,dup", [(5000, 40, False), (4099, 7, True), (20011, 33, False)])
+def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_hubs, dup):
+    """k_spmm_hot: the <= 32 longest rows as a dense MFMA product, everything else gathered.  Checked
+    against the oracle and against the same plan built with TGCN_HOT_ROWS=0, for the float4 kernels
+    (wide, sub-group, > 256 columns), the scalar fallback (complete partition), the transposed block of
+    an asymmetric operator, a split operand and strided results."""
+    gen = torch.Generator().manual_seed(n)
+    ei, w = _hub_graph(n, n_hubs, gen, dup)
+    plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    assert not plan.symmetric
+    for transpose, sel in ((False, _lib.Q_HOT_ROWS), (True, _lib.Q_HOT_ROWS_T)):
+        rp = plan.export_csr(transpose)[0].long()
+        n_long = int(((rp[1:] - rp[:-1]) > 512).sum())           # rows longer than the item weight
+        assert n_long >= min(n_hubs, 7) and plan.query(sel) == min(32, n_long)
+    monkeypatch.setenv("TGCN_HOT_ROWS", "0")
+    plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    assert plain.stats()["hot_rows"] == 0
+    monkeypatch.delenv("TGCN_HOT_ROWS")
+    for F in (200, 64, 8, 132, 260, 520, 7):
+        x = torch.randn(n, F, generator=gen)
+        b = torch.randn(F, generator=gen)
+        xd, bd = x.to(cuda), b.to(cuda)
+        for transpose in (False, True):
+            ref = oracle_spmm(ei, w, n, x, None if transpose else b, transpose=transpose)
+            got = plan.spmm(xd, None if transpose else bd, transpose=transpose)
+            assert rel_err(got, ref) < TOL, (F, transpose)
+            assert rel_err(got, plain.spmm(xd, None if transpose else bd, transpose=transpose)) < TOL
+            assert torch.equal(got, plan.spmm(xd, None if transpose else bd, transpose=transpose))  # reproducible
+        if F % 4 == 0:
+            split = n // 3
+            hi = torch.randn(n, F, device=cuda)
+            hi[11:11 + n - split] = xd[split:]
+            assert torch.equal(plan.spmm(xd[:split].clone(), bd, x2=hi[11:11 + n - split]), plan.spmm(xd, bd))
+            out = torch.full((n, F + 12), 7.0, device=cuda)
+            plan.spmm(xd, bd, out=out[:, 4:4 + F])
+            assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and bool((out[:, :4] == 7).all())
+    plan.close(); plain.close()
+
+
+def test_dense_hot_block_is_chosen_for_the_benchmark_shapes_only_when_it_pays(cuda):
+    g = synth.word_doc_graph(100_000, 2_000_000, seed=44, device=cuda, features="none")     # c2
+    p = GraphPlan(g.edge_index, g.edge_attr, 100_000)
+    assert p.stats()["hot_rows"] == 32 and p.symmetric
+    x = torch.randn(100_000, 200, device=cuda)
+    rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), 100_000)
+    assert rel_err(p.spmm(x), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)) < TOL
+    p.close()
+    g = synth.random_graph(50_000, 400_000, seed=3)                                         # flat degrees
+    p = GraphPlan(g.edge_index.to(cuda), g.edge_attr.to(cuda), 50_000)
+    assert p.stats()["hot_rows"] == 0
+    p.close()
