@@ -345,7 +345,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(args.config, world),
-                         "kernel": "k_spmm_gather (+k_spmm_fix), one tgcn_spmm launch" if parallelism == "single"
+                         "kernel": "one tgcn_spmm launch: k_spmm_gather (+ k_spmm_hot, k_spmm_fix)" if parallelism == "single"
                                    else "one distributed SpMM on this rank: local k_spmm_gather launches + RCCL all-gather / reduce-scatter",
                          "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
                          "algorithmic_bytes_per_launch": launch_bytes},
