@@ -100,7 +100,8 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
     bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
     fused=False: the reference's loop body with its own operators (torch CrossEntropyLoss on
     mask-indexed rows, torch.optim.Adam) around pytextgcn_amd.GCN;  fused=True: the same steps with
-    pytextgcn_amd.functional.masked_cross_entropy and pytextgcn_amd.optim.Adam.
+    pytextgcn_amd.functional.masked_cross_entropy, pytextgcn_amd.optim.Adam and the dropout between the
+    layers fused into the layer-2 GEMMs (pytextgcn_amd.enable_fused_dropout).
     "Metric transfer" (BASELINE.md section 2): the arg-max of the masked logits is taken on the
     device and the PREDICTIONS go to the host; the reference ships the masked logits themselves
     (flat_amazon.py:111-112) and runs numpy / sklearn on them, which is host work outside this path."""
@@ -109,6 +110,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
     N = g.y.numel()
     pkg.enable_activation_reuse(reuse)
     pkg.enable_linear_collapse(collapse)
+    pkg.enable_fused_dropout(fused)          # dropout fused into the next layer's GEMMs (tgcn_gemm_*_dropout)
     model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
     Opt = pkg.optim.Adam if fused else torch.optim.Adam
     opt = Opt(model.parameters(), lr=0.05, amsgrad=True)
@@ -142,6 +144,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
     del model, opt
     pkg.enable_activation_reuse(False)
     pkg.enable_linear_collapse(False)
+    pkg.enable_fused_dropout(False)
     return sorted(times)[len(times) // 2]
 
 

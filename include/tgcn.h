@@ -183,6 +183,23 @@ size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n);
 int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                  int64_t N, int k, int n, void *workspace, size_t workspace_bytes, tgcn_stream stream);
 
+/* The same products with the inverted dropout of the reference's GCN.forward (textgcn/lib/models.py:23,
+ * `x = self.dropout(x)` between the layers) fused in, so that the dropped activation and its mask are
+ * never stored: element (r, c) of the masked [N x w] activation is kept iff hash(seed, r * w + c) >=
+ * p * 2^32 and scaled by 1 / (1 - p); all three regenerate the same mask from `seed` (8 bytes in DEVICE
+ * memory, read by the kernels: safe under HIP-graph capture).
+ *   tgcn_gemm_nn_dropout   C = dropout(A) @ B          mask over A [N x k]   (XW = dropout(H) @ W)
+ *   tgcn_gemm_tn_dropout   C = dropout(A)^T @ G        mask over A [N x k]   (dW = dropout(H)^T @ dXW)
+ *   tgcn_gemm_nt_dropout   C = dropout'(A @ B^T)       mask over C [N x n]   (dH = mask * (dXW @ W^T))
+ * 0 <= p <= 1 (p = 1 yields zeros).  The random stream is this library's own, not torch's. */
+int tgcn_gemm_nn_dropout(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, tgcn_stream stream);
+int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, tgcn_stream stream);
+int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
+                         size_t workspace_bytes, tgcn_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Word-word PMI edges (graph construction).  Replaces the reference's Cython
  * entry point `compute_word_word_edges(X, n_vocab, n_documents, seq_len, window_size, n_jobs, verbose)`

@@ -50,6 +50,12 @@ SIGNATURES = {
     "tgcn_gemm_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "tgcn_gemm_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p, c_size_t, c_void_p]),
+    "tgcn_gemm_nn_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                     c_double, c_void_p, c_void_p]),
+    "tgcn_gemm_nt_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                     c_double, c_void_p, c_void_p]),
+    "tgcn_gemm_tn_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                     c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_wwedges_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p,
                                     POINTER(c_void_p)]),
     "tgcn_wwedges_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),

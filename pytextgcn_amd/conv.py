@@ -175,8 +175,15 @@ class GCNConv(nn.Module):
             with torch.no_grad():
                 self.bias.zero_()
 
-    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None,
+                input_dropout: float = 0.0) -> Tensor:
+        """`input_dropout` > 0 (an extension used by pytextgcn_amd.models.GCN when fused dropout is
+        enabled): the layer sees dropout(x, p) -- training-mode inverted dropout -- fused into x @ W."""
         plan = self.plan(x, edge_index, edge_weight)
+        if input_dropout > 0.0:
+            if x.is_sparse:
+                raise ValueError("input_dropout applies to dense activations")
+            return propagate(plan, dense.xw_dropout(x, self.weight, input_dropout), self.bias)
         if _REUSE and x.is_sparse and x.size(1) == self.in_channels and is_sparse_identity(x):
             # layer 1 of TextGCN: one-hot features, X @ W1 is W1; keep M @ W1 + b1 while W1, b1 are unchanged
             key = _reuse_key(plan, self.weight, self.bias)

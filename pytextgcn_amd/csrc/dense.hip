@@ -27,17 +27,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxSmall = 256;  // k, n <= 256
 
+// Inverted dropout fused into the GEMMs around it (the dropout between the GCN layers,
+// textgcn/lib/models.py:23): element (row, col) of the [N x ld] activation is kept with probability
+// 1 - p and scaled by 1 / (1 - p).  The keep decision is a stateless hash of (seed, row * ld + col)
+// (murmur3 mixing steps), so the forward GEMM (mask on its A operand), the weight-gradient GEMM (mask on
+// its A operand) and the input-gradient GEMM (mask on its result) regenerate the SAME mask from the
+// 8-byte seed instead of storing N x ld bytes.  The seed is read from device memory (graph capture).
+struct Drop {
+    const uint64_t *seed;  // device pointer
+    uint32_t thresh;       // keep iff hash >= thresh;  thresh = p * 2^32
+    float scale;           // 1 / (1 - p)
+    int ld;                // logical width of the masked matrix
+};
+
+__device__ __forceinline__ float drop_apply(float v, uint32_t s_lo, uint32_t s_hi, int64_t row, int col,
+                                            const Drop &d) {
+    const uint64_t idx = uint64_t(row) * uint32_t(d.ld) + uint32_t(col);
+    uint32_t h = uint32_t(idx) ^ s_lo;
+    h *= 0xcc9e2d51u;
+    h = (h << 15) | (h >> 17);
+    h *= 0x1b873593u;
+    h ^= uint32_t(idx >> 32) + s_hi;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h >= d.thresh ? v * d.scale : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C[N, n] = A[N, k] @ Bs, where Bs[kk][j] is the small operand staged in LDS as [kpad][npad].
 // One wave per 32 rows, NT tiles of 32 columns each (npad = 32*NT).  TRANS_B selects how the small
 // operand is read from memory: B[k][n] (nn) or B[n][k] (nt).
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool TRANS_B, bool K8, int NQ>
+// DROP: nn (TRANS_B = false) masks the A operand, nt (TRANS_B = true) masks the result.
+template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP>
 __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
-                                                   int k, int n) {
+                                                   int k, int n, const Drop drop) {
     extern __shared__ float lds[];  // [kpad][npad]
+    uint32_t s_lo = 0, s_hi = 0;
+    if constexpr (DROP) {
+        const uint64_t sd = *drop.seed;
+        s_lo = uint32_t(sd);
+        s_hi = uint32_t(sd >> 32);
+    }
     constexpr int npad = 32 * NT;
     const int kpad = (k + 7) & ~7;
     // stage the small operand, zero padded
@@ -112,7 +148,12 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
                 else
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[q & 7])::"memory");
                 const f32x4 a = ring[q & 7];
-                const float av[4] = {a[0], a[1], a[2], a[3]};
+                float av[4] = {a[0], a[1], a[2], a[3]};
+                if constexpr (DROP && !TRANS_B) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        av[s4] = drop_apply(av[s4], s_lo, s_hi, row, 8 * q + 4 * half + s4, drop);
+                }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -140,7 +181,12 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
 #pragma unroll
                     for (int t = 0; t < NT; ++t) bnxt[s4][t] = bq[s4 * npad + 32 * t];
             }
-            const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+            float av[4] = {a0.x, a0.y, a0.z, a0.w};
+            if constexpr (DROP && !TRANS_B) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    av[s4] = drop_apply(av[s4], s_lo, s_hi, row, 8 * q + 4 * half + s4, drop);
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -163,7 +209,9 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    if (orow < N) C[orow * ldc + col] = acc[t][i];
+                    float out = acc[t][i];
+                    if constexpr (DROP && TRANS_B) out = drop_apply(out, s_lo, s_hi, orow, col, drop);
+                    if (orow < N) C[orow * ldc + col] = out;
                 }
             }
         }
@@ -176,11 +224,17 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
 // lanes 0-31 / 32-63 read 32 consecutive floats of row 2s / 2s+1 (two coalesced 128-byte segments).
 // 4 waves per workgroup; wave w owns the M-tiles {w, w+4} (of kpad/32 <= 8) x all NT column tiles.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restrict__ A, int64_t lda,
                                                             const float *__restrict__ G, int64_t ldg,
                                                             int64_t N, int k, int n, int64_t rows_per_wg,
-                                                            float *__restrict__ partial) {
+                                                            float *__restrict__ partial, const Drop drop) {
+    uint32_t s_lo = 0, s_hi = 0;
+    if constexpr (DROP) {
+        const uint64_t sd = *drop.seed;
+        s_lo = uint32_t(sd);
+        s_hi = uint32_t(sd >> 32);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, half = lane >> 5;
     const int mt = (k + 31) / 32;  // M tiles
@@ -208,7 +262,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
     const int64_t n_rows = r_end > r_begin ? r_end - r_begin : 0;
     const int64_t n_full = n_rows / (2 * UR);
     float a0[2][UR], a1[2][UR], g[2][UR][NT];
+    const int ca0 = std::min(32 * m0 + c, k - 1), ca1 = std::min(32 * m1 + c, k - 1);   // columns of A this lane reads
+    int64_t next_row = r_begin + half, stage_row[2] = {0, 0};
     auto load_stage = [&](int buf) {
+        stage_row[buf] = next_row;
+        next_row += 2 * UR;
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             a0[buf][u] = pa0[int64_t(2 * u) * lda];
@@ -223,12 +281,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
     };
     auto mfma_stage = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < UR; ++u)
+        for (int u = 0; u < UR; ++u) {
+            float x0 = a0[buf][u], x1 = a1[buf][u];
+            if constexpr (DROP) {
+                x0 = drop_apply(x0, s_lo, s_hi, stage_row[buf] + 2 * u, ca0, drop);
+                x1 = drop_apply(x1, s_lo, s_hi, stage_row[buf] + 2 * u, ca1, drop);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[buf][u], g[buf][u][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[buf][u], g[buf][u][t], acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, g[buf][u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, g[buf][u][t], acc[1][t], 0, 0, 0);
             }
+        }
     };
     if (n_full > 0) load_stage(0);
     for (int64_t it = 0; it < n_full; it += 2) {
@@ -244,7 +308,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         const bool ok = r + half < n_rows;
         const int64_t back = ok ? 0 : 1;      // the odd last row: re-read the previous one, scaled by 0
         const float s = ok ? 1.f : 0.f;
-        const float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
+        float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
+        if constexpr (DROP) {
+            x0 = drop_apply(x0, s_lo, s_hi, r_begin + r + half - back, ca0, drop);
+            x1 = drop_apply(x1, s_lo, s_hi, r_begin + r + half - back, ca1, drop);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float y = pg[t][-back * ldg] * s;
@@ -305,9 +373,9 @@ int tn_blocks(int64_t N) {
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(nb, 512)));
 }
 
-template <bool TRANS_B>
+template <bool TRANS_B, bool DROP>
 int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                int64_t N, int k, int n, hipStream_t s) {
+                int64_t N, int k, int n, const Drop drop, hipStream_t s) {
     const int nt = (n + 31) / 32;
     const int kpad = (k + 7) & ~7;
     const size_t lds_bytes = sizeof(float) * static_cast<size_t>(kpad) * (32 * nt);
@@ -327,7 +395,7 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
     }
 #define TGCN_TALL_K(NT, K8, NQ_)                                                                     \
     do {                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_>);      \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP>);      \
         TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                            static_cast<int>(lds_bytes)));                         \
         int per_cu = 1;                                                                           \
@@ -335,7 +403,7 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         per_cu = std::max(1, std::min(per_cu, 4));                                                \
         const int grid = static_cast<int>(                                                        \
             std::max<int64_t>(1, std::min<int64_t>((n_blocks + 3) / 4, int64_t(n_cu) * per_cu))); \
-        k_gemm_tall<NT, TRANS_B, K8, NQ_><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n); \
+        k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, drop); \
     } while (0)
 #define TGCN_TALL(NT)                                                                             \
     do {                                                                                          \
@@ -385,28 +453,74 @@ int check_common(const char *fn, const void *a, const void *b, const void *c, in
 
 extern "C" {
 
-int tgcn_gemm_nn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                 int64_t N, int k, int n, tgcn_stream stream) {
+static int gemm_nn_impl(const char *fn, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                        int64_t ldc, int64_t N, int k, int n, const tgcn::Drop *drop, tgcn_stream stream) {
     using namespace tgcn;
-    TGCN_CHECK(check_common("tgcn_gemm_nn", A, B, C, N, k, n));
+    TGCN_CHECK(check_common(fn, A, B, C, N, k, n));
     if (lda < k || ldb < n || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
-        set_error("tgcn_gemm_nn: need lda >= k, ldb, ldc >= n, lda %% 4 == 0 and A 16-byte aligned");
+        set_error("%s: need lda >= k, ldb, ldc >= n, lda %% 4 == 0 and A 16-byte aligned", fn);
         return TGCN_E_INVALID;
     }
     if (N == 0) return TGCN_OK;
-    return launch_tall<false>(A, lda, B, ldb, C, ldc, N, k, n, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return drop ? launch_tall<false, true>(A, lda, B, ldb, C, ldc, N, k, n, *drop, s)
+                : launch_tall<false, false>(A, lda, B, ldb, C, ldc, N, k, n, Drop{}, s);
+}
+
+static int gemm_nt_impl(const char *fn, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                        int64_t ldc, int64_t N, int k, int n, const tgcn::Drop *drop, tgcn_stream stream) {
+    using namespace tgcn;
+    TGCN_CHECK(check_common(fn, A, B, C, N, k, n));
+    if (lda < k || ldb < k || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
+        set_error("%s: need lda, ldb >= k, ldc >= n, lda %% 4 == 0 and A 16-byte aligned", fn);
+        return TGCN_E_INVALID;
+    }
+    if (N == 0) return TGCN_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return drop ? launch_tall<true, true>(A, lda, B, ldb, C, ldc, N, k, n, *drop, s)
+                : launch_tall<true, false>(A, lda, B, ldb, C, ldc, N, k, n, Drop{}, s);
+}
+
+// p in [0, 1]; p = 1 drops everything (scale 0, as torch does)
+static int make_drop(const char *fn, double p, const uint64_t *seed, int ld, tgcn::Drop &d) {
+    if (!(p >= 0.0 && p <= 1.0) || !seed) {
+        tgcn::set_error("%s: need 0 <= p <= 1 and a non-NULL device seed (p=%g)", fn, p);
+        return TGCN_E_INVALID;
+    }
+    d.seed = seed;
+    d.ld = ld;
+    if (p >= 1.0) {
+        d.thresh = 0xffffffffu;
+        d.scale = 0.f;
+    } else {
+        d.thresh = static_cast<uint32_t>(std::min(p * 4294967296.0, 4294967295.0));
+        d.scale = static_cast<float>(1.0 / (1.0 - p));
+    }
+    return TGCN_OK;
+}
+
+int tgcn_gemm_nn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 int64_t N, int k, int n, tgcn_stream stream) {
+    return gemm_nn_impl("tgcn_gemm_nn", A, lda, B, ldb, C, ldc, N, k, n, nullptr, stream);
 }
 
 int tgcn_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                  int64_t N, int k, int n, tgcn_stream stream) {
-    using namespace tgcn;
-    TGCN_CHECK(check_common("tgcn_gemm_nt", A, B, C, N, k, n));
-    if (lda < k || ldb < k || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
-        set_error("tgcn_gemm_nt: need lda, ldb >= k, ldc >= n, lda %% 4 == 0 and A 16-byte aligned");
-        return TGCN_E_INVALID;
-    }
-    if (N == 0) return TGCN_OK;
-    return launch_tall<true>(A, lda, B, ldb, C, ldc, N, k, n, static_cast<hipStream_t>(stream));
+    return gemm_nt_impl("tgcn_gemm_nt", A, lda, B, ldb, C, ldc, N, k, n, nullptr, stream);
+}
+
+int tgcn_gemm_nn_dropout(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, tgcn_stream stream) {
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop("tgcn_gemm_nn_dropout", p, seed, k, d));
+    return gemm_nn_impl("tgcn_gemm_nn_dropout", A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
+}
+
+int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, tgcn_stream stream) {
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop("tgcn_gemm_nt_dropout", p, seed, n, d));
+    return gemm_nt_impl("tgcn_gemm_nt_dropout", A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
 }
 
 size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {
@@ -415,17 +529,18 @@ size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {
     return sizeof(float) * static_cast<size_t>(tgcn::tn_blocks(N)) * mpad * npad;
 }
 
-int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
-                 int64_t N, int k, int n, void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float *G, int64_t ldg, float *C,
+                        int64_t ldc, int64_t N, int k, int n, void *workspace, size_t workspace_bytes,
+                        const tgcn::Drop *drop, tgcn_stream stream) {
     using namespace tgcn;
-    TGCN_CHECK(check_common("tgcn_gemm_tn", A, G, C, N, k, n));
+    TGCN_CHECK(check_common(fn, A, G, C, N, k, n));
     if (lda < k || ldg < n || ldc < n) {
-        set_error("tgcn_gemm_tn: need lda >= k and ldg, ldc >= n");
+        set_error("%s: need lda >= k and ldg, ldc >= n", fn);
         return TGCN_E_INVALID;
     }
     const size_t need = tgcn_gemm_tn_workspace_bytes(N, k, n);
     if (!workspace || workspace_bytes < need) {
-        set_error("tgcn_gemm_tn: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        set_error("%s: workspace of %zu bytes given, %zu needed", fn, workspace_bytes, need);
         return TGCN_E_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -433,19 +548,41 @@ int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float
     const int64_t rows_per_wg = ((N + nb - 1) / nb + 1) & ~int64_t(1);  // even: steps are row pairs
     const int nt = (n + 31) / 32, mt = (k + 31) / 32;
     float *partial = static_cast<float *>(workspace);
+#define TGCN_TN(NT)                                                                                          \
+    do {                                                                                                     \
+        if (drop)                                                                                            \
+            k_gemm_tn_partial<NT, true><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial, *drop); \
+        else                                                                                                 \
+            k_gemm_tn_partial<NT, false><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial, Drop{}); \
+    } while (0)
     switch (nt) {
-        case 1: k_gemm_tn_partial<1><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
-        case 2: k_gemm_tn_partial<2><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
-        case 3: k_gemm_tn_partial<3><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
-        case 4: k_gemm_tn_partial<4><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial); break;
+        case 1: TGCN_TN(1); break;
+        case 2: TGCN_TN(2); break;
+        case 3: TGCN_TN(3); break;
+        case 4: TGCN_TN(4); break;
         default:
-            set_error("tgcn_gemm_tn: n = %d > 128 is not instantiated (use tgcn_gemm_tn with the roles of A and G swapped)", n);
+            set_error("%s: n = %d > 128 is not instantiated (use tgcn_gemm_tn with the roles of A and G swapped)", fn, n);
             return TGCN_E_INVALID;
     }
+#undef TGCN_TN
     TGCN_HIP_CHECK(hipGetLastError());
     k_gemm_tn_reduce<<<(k * n + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mt, 32 * nt, k, n, C, ldc);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
+}
+
+int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                 int64_t N, int k, int n, void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+    return gemm_tn_impl("tgcn_gemm_tn", A, lda, G, ldg, C, ldc, N, k, n, workspace, workspace_bytes, nullptr, stream);
+}
+
+int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                         int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
+                         size_t workspace_bytes, tgcn_stream stream) {
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop("tgcn_gemm_tn_dropout", p, seed, k, d));
+    return gemm_tn_impl("tgcn_gemm_tn_dropout", A, lda, G, ldg, C, ldc, N, k, n, workspace, workspace_bytes, &d,
+                        stream);
 }
 
 }  // extern "C"

@@ -32,31 +32,45 @@ def _rowmajor4(t: Tensor) -> Tensor:
     return t
 
 
-def gemm_nn(a: Tensor, b: Tensor) -> Tensor:
+def _check_seed(seed: Tensor, dev) -> None:
+    if seed.dtype != torch.int64 or seed.numel() != 1 or seed.device != dev:
+        raise TypeError("dropout seed must be a one-element int64 tensor on the operand's device")
+
+
+def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
+    """a [N, k] @ b [k, n]; with `seed`: dropout(a, p) @ b, the mask regenerated from the seed."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(1)
     c = torch.empty(N, n, dtype=torch.float32, device=a.device)
-    _lib.check(lib.tgcn_gemm_nn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
-                                c.stride(0), N, k, n, _stream_ptr(a.device)))
+    args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
+    if seed is None:
+        _lib.check(lib.tgcn_gemm_nn(*args, _stream_ptr(a.device)))
+    else:
+        _check_seed(seed, a.device)
+        _lib.check(lib.tgcn_gemm_nn_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
     return c
 
 
-def gemm_nt(a: Tensor, b: Tensor) -> Tensor:
-    """a [N, k] @ b[n, k]^T"""
+def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
+    """a [N, k] @ b[n, k]^T; with `seed` the [N, n] result is masked and scaled (dropout backward)."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(0)
     c = torch.empty(N, n, dtype=torch.float32, device=a.device)
-    _lib.check(lib.tgcn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
-                                c.stride(0), N, k, n, _stream_ptr(a.device)))
+    args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
+    if seed is None:
+        _lib.check(lib.tgcn_gemm_nt(*args, _stream_ptr(a.device)))
+    else:
+        _check_seed(seed, a.device)
+        _lib.check(lib.tgcn_gemm_nt_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
     return c
 
 
-def gemm_tn(a: Tensor, g: Tensor) -> Tensor:
-    """a[N, k]^T @ g[N, n]"""
+def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
+    """a[N, k]^T @ g[N, n]; with `seed`: dropout(a, p)^T @ g."""
     lib = _lib.load()
     if a.stride(1) != 1:
         a = a.contiguous()
@@ -67,8 +81,13 @@ def gemm_tn(a: Tensor, g: Tensor) -> Tensor:
     c = torch.empty(k, n, dtype=torch.float32, device=a.device)
     ws_bytes = lib.tgcn_gemm_tn_workspace_bytes(N, k, n)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=a.device)
-    _lib.check(lib.tgcn_gemm_tn(a.data_ptr(), a.stride(0), g.data_ptr(), g.stride(0), c.data_ptr(),
-                                c.stride(0), N, k, n, ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
+    args = (a.data_ptr(), a.stride(0), g.data_ptr(), g.stride(0), c.data_ptr(), c.stride(0), N, k, n)
+    if seed is None:
+        _lib.check(lib.tgcn_gemm_tn(*args, ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
+    else:
+        _check_seed(seed, a.device)
+        _lib.check(lib.tgcn_gemm_tn_dropout(*args, float(p), seed.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream_ptr(a.device)))
     return c
 
 
@@ -84,6 +103,39 @@ class _XW(torch.autograd.Function):
         dx = gemm_nt(g, w) if ctx.needs_input_grad[0] else None        # g @ w^T
         dw = gemm_tn(x, g) if ctx.needs_input_grad[1] else None        # x^T @ g
         return dx, dw
+
+
+class _XWDropout(torch.autograd.Function):
+    """dropout(x, p) @ w with the mask regenerated in all three GEMMs (never stored)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, p: float, seed: Tensor):
+        ctx.save_for_backward(x, w, seed)
+        ctx.p = p
+        return gemm_nn(x.detach(), w.detach(), p, seed)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w, seed = ctx.saved_tensors
+        dx = gemm_nt(g, w, ctx.p, seed) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
+        dw = gemm_tn(x, g, ctx.p, seed) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
+        return dx, dw, None, None
+
+
+def new_seed(device) -> Tensor:
+    """A fresh 64-bit seed drawn ON the device from torch's generator (no host sync; under HIP-graph
+    capture every replay draws a new one)."""
+    return torch.empty(1, dtype=torch.int64, device=device).random_()
+
+
+def xw_dropout(x: Tensor, w: Tensor, p: float, seed: Tensor = None) -> Tensor:
+    """dropout(x, p) @ w (training-mode inverted dropout, textgcn/lib/models.py:23 followed by the next
+    layer's x @ W) as ONE pass over x.  Falls back to torch's dropout + matmul for unsupported shapes."""
+    if p <= 0.0:
+        return xw(x, w)
+    if supported(x, w):
+        return _XWDropout.apply(x, w, float(p), new_seed(x.device) if seed is None else seed)
+    return torch.matmul(torch.nn.functional.dropout(x, p, True), w)
 
 
 def xw(x: Tensor, w: Tensor) -> Tensor:

@@ -28,6 +28,18 @@ def enable_linear_collapse(on: bool = True) -> None:
     _COLLAPSE = bool(on)
 
 
+# Opt-in: the dropout between the layers (models.py:23) fused into the next layer's x @ W and its
+# autograd (libtgcn.so tgcn_gemm_*_dropout): neither the dropped activation nor its mask is stored, the
+# three GEMMs regenerate the mask from an 8-byte seed.  Same distribution as torch's dropout, but the
+# random stream is the library's own (seeded from torch's generator), hence off by default.
+_FUSED_DROPOUT = False
+
+
+def enable_fused_dropout(on: bool = True) -> None:
+    global _FUSED_DROPOUT
+    _FUSED_DROPOUT = bool(on)
+
+
 class GCN(nn.Module):
     def __init__(self, in_channels, out_channels, n_gcn=2, n_hidden_gcn=64, activation=nn.ReLU,
                  dropout=0.5):
@@ -58,8 +70,14 @@ class GCN(nn.Module):
                 and (not self.training or self.dropout == 0)):
             return self._collapsed_forward(g)
         x = g.x
+        pending = 0.0                          # dropout still owed to x (fused into the next layer)
         for i, layer in enumerate(self.layers):
-            x = layer(x, g.edge_index, g.edge_attr)
+            x = layer(x, g.edge_index, g.edge_attr, input_dropout=pending) if pending > 0.0 \
+                else layer(x, g.edge_index, g.edge_attr)
+            pending = 0.0
             if i < len(self.layers) - 1:
-                x = nn.functional.dropout(x, p=self.dropout, training=self.training)
+                if _FUSED_DROPOUT and self.training and 0.0 < self.dropout < 1.0 and not x.is_sparse:
+                    pending = float(self.dropout)
+                else:
+                    x = nn.functional.dropout(x, p=self.dropout, training=self.training)
         return x

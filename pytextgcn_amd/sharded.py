@@ -66,6 +66,10 @@ class HipEngine:
         from . import dense
         return dense.xw(x, w)                 # fp32 MFMA kernels, with autograd
 
+    def xw_dropout(self, x: Tensor, w: Tensor, p: float) -> Tensor:
+        from . import dense
+        return dense.xw_dropout(x, w, p)      # dropout fused into the three GEMMs (mask never stored)
+
     def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int) -> Tensor:
         from .functional import masked_cross_entropy
         return masked_cross_entropy(logits, y, mask, count=count)
@@ -310,10 +314,13 @@ class ShardedGCN(nn.Module):
     def forward(self, g=None) -> Tensor:
         """Logits of this rank's rows, [n_local, out_channels] (padding rows hold the bias)."""
         x = sharded_propagate(self.sg, self.weights[0], self.biases[0])
+        eng = self.sg.engine
         for i in range(1, len(self.weights)):
-            x = nn.functional.dropout(x, p=self.dropout, training=self.training)
-            xw = self.sg.engine.xw(x, self.weights[i]) if hasattr(self.sg.engine, "xw") \
-                else torch.matmul(x, self.weights[i])
+            if self.training and 0.0 < self.dropout < 1.0 and hasattr(eng, "xw_dropout"):
+                xw = eng.xw_dropout(x, self.weights[i], float(self.dropout))
+            else:
+                x = nn.functional.dropout(x, p=self.dropout, training=self.training)
+                xw = eng.xw(x, self.weights[i]) if hasattr(eng, "xw") else torch.matmul(x, self.weights[i])
             x = sharded_propagate(self.sg, xw, self.biases[i])
         return x
 

@@ -910,3 +910,98 @@ def test_dense_hot_block_is_chosen_for_the_benchmark_shapes_only_when_it_pays(cu
     p = GraphPlan(g.edge_index.to(cuda), g.edge_attr.to(cuda), 50_000)
     assert p.stats()["hot_rows"] == 0
     p.close()
+
+
+def _drop_mask(N, h, p, seed, cuda):
+    """The keep mask of the fused dropout over an [N, h] activation, read back through the nt product:
+    mask * (ones[N,8] @ ones[h,8]^T) / (1 - p) = 8 mask / (1 - p)."""
+    from pytextgcn_amd import dense
+    out = dense.gemm_nt(torch.ones(N, 8, device=cuda), torch.ones(h, 8, device=cuda), p, seed)
+    keep = out != 0
+    assert torch.allclose(out[keep], torch.full_like(out[keep], 8.0 / (1.0 - p)), rtol=1e-6)
+    return keep
+
+
+@pytest.mark.parametrize("N,h,C,p", [(100_000, 200, 64, 0.5), (4097, 100, 20, 0.7), (333, 30, 7, 0.2),
+                                     (64, 64, 64, 0.5), (1, 8, 3, 0.5)])
+def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
+    """tgcn_gemm_{nn,tn,nt}_dropout regenerate the same mask from the seed: forward, weight gradient
+    and input gradient agree with the explicit-mask formulas (float64); keep rate = 1 - p."""
+    from pytextgcn_amd import dense
+    gen = torch.Generator(device=cuda).manual_seed(N + h)
+    seed = torch.randint(-2**62, 2**62, (1,), device=cuda, generator=gen)
+    keep = _drop_mask(N, h, p, seed, cuda)
+    if N * h >= 10_000:
+        rate = keep.float().mean().item()
+        assert abs(rate - (1 - p)) < 5 * (p * (1 - p) / (N * h)) ** 0.5 + 1e-4
+        assert abs(keep.float().mean(0) - (1 - p)).max() < 6 * (p * (1 - p) / N) ** 0.5 + 1e-3     # no dead columns
+        other = _drop_mask(N, h, p, seed + 1, cuda)
+        assert 0.3 < (other ^ keep).float().mean().item() / (2 * p * (1 - p)) < 1.7                   # independent
+    assert torch.equal(keep, _drop_mask(N, h, p, seed.clone(), cuda))
+    x = torch.randn(N, h, device=cuda, generator=gen)
+    w = torch.randn(h, C, device=cuda, generator=gen)
+    g = torch.randn(N, C, device=cuda, generator=gen)
+    xd = (x * keep).double() / (1 - p)
+    assert rel_err(dense.gemm_nn(x, w, p, seed), xd @ w.double()) < TOL
+    assert rel_err(dense.gemm_tn(x, g, p, seed), xd.t() @ g.double()) < TOL
+    assert rel_err(dense.gemm_nt(g, w, p, seed), (g.double() @ w.double().t()) * keep / (1 - p)) < TOL
+    # autograd wrapper
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    out = dense.xw_dropout(xr, wr, p, seed)
+    out.backward(g)
+    assert rel_err(out, xd @ w.double()) < TOL
+    assert rel_err(wr.grad, xd.t() @ g.double()) < TOL
+    assert rel_err(xr.grad, (g.double() @ w.double().t()) * keep / (1 - p)) < TOL
+    # p = 0 and p = 1
+    assert rel_err(dense.gemm_nn(x, w, 0.0, seed), x.double() @ w.double()) < TOL
+    assert float(dense.gemm_nn(x, w, 1.0, seed).abs().max()) == 0.0
+
+
+def test_gcn_with_fused_dropout(cuda):
+    """pytextgcn_amd.enable_fused_dropout(): training forward/backward of the 2-layer GCN equal the oracle's with the
+    SAME mask applied explicitly between the layers; eval mode and dropout = 0 are untouched; a fresh
+    mask is drawn per call."""
+    from pytextgcn_amd import dense
+    N, C, H, p = 4000, 12, 200, 0.5
+    g = synth.word_doc_graph(N, 60000, seed=8, n_classes=C)
+    torch.manual_seed(1)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=H, dropout=p)
+    mine = pkg.GCN(N, C, n_hidden_gcn=H, dropout=p)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    seeds = []
+    real_new_seed = dense.new_seed
+
+    def recording_seed(device):
+        seeds.append(real_new_seed(device))
+        return seeds[-1]
+
+    pkg.enable_fused_dropout(True)
+    dense.new_seed = recording_seed
+    try:
+        mine.train()
+        out = mine(gd)
+        loss = torch.nn.functional.cross_entropy(out[gd.train_mask], gd.y[gd.train_mask])
+        loss.backward()
+        out2 = mine(gd)
+        assert len(seeds) == 2 and not torch.equal(out, out2)
+        mine.eval()
+        with torch.no_grad():
+            ev = mine(gd)
+        assert len(seeds) == 2
+    finally:
+        dense.new_seed = real_new_seed
+        pkg.enable_fused_dropout(False)
+    keep = _drop_mask(N, H, p, seeds[0], cuda).cpu()
+    # oracle with the explicit mask between the layers
+    h1 = ref.layers[0](g.x, g.edge_index, g.edge_attr)
+    want = ref.layers[1](h1 * keep / (1 - p), g.edge_index, g.edge_attr)
+    lo = torch.nn.functional.cross_entropy(want[g.train_mask], g.y[g.train_mask])
+    lo.backward()
+    assert rel_err(out, want) < TOL and abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad, pr.grad) < 5 * TOL, k
+    ref.eval()
+    with torch.no_grad():
+        assert rel_err(ev, ref(g)) < TOL

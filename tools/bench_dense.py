@@ -34,3 +34,14 @@ for name, mine, ref, flop, byt in [
 ]:
     a, b = t(mine), t(ref)
     print(f"{name} mfma kernel {a:7.3f} ms ({flop / a / 1e9:6.1f} TF/s, {byt / a / 1e6:6.0f} GB/s)   torch.matmul {b:7.3f} ms")
+
+# the same three with the dropout between the layers fused in (tgcn_gemm_*_dropout) against what they
+# replace: torch's dropout kernel + GEMM (forward), mask multiply + GEMM (backward)
+seed = dense.new_seed(dev)
+for name, mine, ref in [
+    ("nn  dropout(H) @ W   ", lambda: dense.gemm_nn(H, W, 0.5, seed), lambda: dense.gemm_nn(torch.nn.functional.dropout(H, 0.5, True), W)),
+    ("nt  mask * (G @ W^T) ", lambda: dense.gemm_nt(G, W, 0.5, seed), lambda: dense.gemm_nt(G, W) * 2.0),
+    ("tn  dropout(H)^T @ G ", lambda: dense.gemm_tn(H, G, 0.5, seed), lambda: dense.gemm_tn(H, G)),
+]:
+    a, b = t(mine), t(ref)
+    print(f"{name} fused {a:7.3f} ms   unfused (separate elementwise pass where there is one) {b:7.3f} ms")
