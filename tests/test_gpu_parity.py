@@ -1005,3 +1005,22 @@ def test_gcn_with_fused_dropout(cuda):
     ref.eval()
     with torch.no_grad():
         assert rel_err(ev, ref(g)) < TOL
+
+
+def test_graphed_training_with_fused_dropout_draws_a_new_mask_per_replay(cuda):
+    """The seed of the fused dropout is drawn on the device inside the captured step, so every replay
+    of the HIP graph uses a fresh mask (a frozen mask would repeat the same loss on frozen weights)."""
+    from pytextgcn_amd.train import GraphedTrainStep
+    N, C = 3000, 6
+    g = synth.word_doc_graph(N, 40000, seed=27, n_classes=C, device=cuda)
+    torch.manual_seed(3)
+    model = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.5).to(cuda)
+    opt = pkg.optim.Adam(model.parameters(), lr=0.0, amsgrad=True, capturable=True)   # lr 0: weights frozen
+    pkg.enable_fused_dropout(True)
+    try:
+        step = GraphedTrainStep(model, g, opt, g.train_mask, warmup=1)
+        losses = [step().item() for _ in range(5)]
+    finally:
+        pkg.enable_fused_dropout(False)
+    assert len(set(losses)) == 5 and all(np.isfinite(losses))
+    assert max(losses) - min(losses) < 0.2 * abs(losses[0])          # same weights, different masks
