@@ -41,7 +41,28 @@ def counters(d):
     return agg
 
 
+def epoch_table():
+    """summarize.py epoch <tag> <stats_dir> <n_epochs>: per-epoch kernel table of tools/profile_epoch.py"""
+    tag, d, n = sys.argv[2], sys.argv[3], int(sys.argv[4])
+    rows = kernel_stats(d)
+    total = sum(float(r["TotalDurationNs"]) for r in rows) / n / 1e6
+    lines = [f"# Kernel time per epoch of the fused loop, {tag}", "",
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/profile_epoch.py"
+             f"{(' ' + sys.argv[5]) if len(sys.argv) > 5 else ''}` (config c4; {n} epochs in the trace, graph "
+             "generation and plan construction included in the tail rows).", "",
+             f"Sum of kernel durations: {total:.2f} ms per epoch.", "",
+             "| kernel | us / epoch | calls / epoch | % |", "|---|---|---|---|"]
+    for r in rows[:24]:
+        lines.append(f"| `{short(r['Name'])}` | {float(r['TotalDurationNs']) / n / 1e3:.1f} | "
+                     f"{float(r['Calls']) / n:.1f} | {r['Percentage']} |")
+    with open(os.path.join(HERE, f"{tag}_epoch_kernels.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 def main():
+    if sys.argv[1] == "epoch":
+        return epoch_table()
     tag, stats_dir = sys.argv[1], sys.argv[2]
     lines = [f"# rocprofv3 summary, round {tag}", ""]
     cmd_file = os.path.join(stats_dir, "..", "command.txt")

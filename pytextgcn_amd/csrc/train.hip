@@ -10,6 +10,7 @@
 // Both are deterministic (fixed-order two-stage reductions, no atomics).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -99,7 +100,30 @@ __global__ void k_adam_scalars(int64_t *step, double lr, double b1, double b2, f
     scalars[1] = static_cast<float>(1.0 / sqrt(bc2));
 }
 
-template <bool AMSGRAD>
+// NT: the optimizer state (m, v, vmax) and the gradient are touched once per step -- stream them past
+// the caches with non-temporal loads / stores; the parameter itself is the next SpMM's operand and
+// keeps plain accesses.
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float *q) {
+    if constexpr (NT) {
+        const adam_f4 t = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(q));
+        return make_float4(t.x, t.y, t.z, t.w);
+    } else {
+        return *reinterpret_cast<const float4 *>(q);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float *q, const float4 &a) {
+    if constexpr (NT) {
+        adam_f4 t = {a.x, a.y, a.z, a.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<adam_f4 *>(q));
+    } else {
+        *reinterpret_cast<float4 *>(q) = a;
+    }
+}
+
+template <bool AMSGRAD, bool NT>
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
                                               float *__restrict__ m, float *__restrict__ v,
                                               float *__restrict__ vmax, int64_t n, float w1 /* 1-b1 */,
@@ -114,11 +138,11 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
     for (int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
             float4 pp = *reinterpret_cast<float4 *>(p + i);
-            const float4 gg = *reinterpret_cast<const float4 *>(g + i);
-            float4 mm = *reinterpret_cast<float4 *>(m + i);
-            float4 vv = *reinterpret_cast<float4 *>(v + i);
+            const float4 gg = ld4<NT>(g + i);
+            float4 mm = ld4<NT>(m + i);
+            float4 vv = ld4<NT>(v + i);
             float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (AMSGRAD) xx = *reinterpret_cast<float4 *>(vmax + i);
+            if (AMSGRAD) xx = ld4<NT>(vmax + i);
             float *P = &pp.x, *M = &mm.x, *V = &vv.x, *X = &xx.x;
             const float *G = &gg.x;
 #pragma unroll
@@ -135,9 +159,9 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
                 P[k] = P[k] - step_size * (M[k] / denom);
             }
             *reinterpret_cast<float4 *>(p + i) = pp;
-            *reinterpret_cast<float4 *>(m + i) = mm;
-            *reinterpret_cast<float4 *>(v + i) = vv;
-            if (AMSGRAD) *reinterpret_cast<float4 *>(vmax + i) = xx;
+            st4<NT>(m + i, mm);
+            st4<NT>(v + i, vv);
+            if (AMSGRAD) st4<NT>(vmax + i, xx);
         } else {
             for (int64_t j = i; j < n; ++j) {
                 const float gr = g[j] + wd * p[j];
@@ -254,12 +278,21 @@ static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp
         k_adam_scalars<<<1, 1, 0, s>>>(step_dev, lr, beta1, beta2, scalars_dev);
         TGCN_HIP_CHECK(hipGetLastError());
     }
-    if (max_exp_avg_sq)
-        k_adam<true><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, w1, b2f, w2,
-                                          epsf, wdf, step_size, inv_bc2_sqrt, scalars_dev);
-    else
-        k_adam<false><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, nullptr, n, w1, b2f, w2, epsf,
-                                           wdf, step_size, inv_bc2_sqrt, scalars_dev);
+    // large tensors (W1: N x h) stream their state past the caches; TGCN_ADAM_NT=0/1 forces either form
+    static const int nt_env = [] {
+        const char *e = std::getenv("TGCN_ADAM_NT");
+        return e ? std::atoi(e) : -1;
+    }();
+    const bool nt = nt_env >= 0 ? nt_env != 0 : n >= (int64_t(1) << 24);
+#define TGCN_ADAM(AMS, NTV)                                                                                  \
+    k_adam<AMS, NTV><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, AMS ? max_exp_avg_sq : nullptr, n, w1, \
+                                          b2f, w2, epsf, wdf, step_size, inv_bc2_sqrt, scalars_dev)
+    if (max_exp_avg_sq) {
+        if (nt) TGCN_ADAM(true, true); else TGCN_ADAM(true, false);
+    } else {
+        if (nt) TGCN_ADAM(false, true); else TGCN_ADAM(false, false);
+    }
+#undef TGCN_ADAM
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }

@@ -400,6 +400,24 @@ def test_fused_adam_matches_torch(cuda, amsgrad, wd):
     assert rel_err(st["exp_avg_sq"], o_r.state[ref_p[0]]["exp_avg_sq"]) < TOL
 
 
+def test_fused_adam_streaming_path_for_large_tensors(cuda):
+    """>= 2^24 elements take the non-temporal (streaming) form of k_adam: same numbers as torch's Adam
+    on the device, including the ragged tail."""
+    from pytextgcn_amd.optim import Adam
+    n = (1 << 24) + 5
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    pm = torch.randn(n, device=cuda, generator=gen).requires_grad_()
+    pr = pm.detach().clone().requires_grad_()
+    o_r = torch.optim.Adam([pr], lr=0.05, amsgrad=True)
+    o_m = Adam([pm], lr=0.05, amsgrad=True)
+    for step in range(3):
+        g = torch.randn(n, device=cuda, generator=gen)
+        pr.grad, pm.grad = g, g.clone()
+        o_r.step(), o_m.step()
+    assert rel_err(pm, pr) < TOL
+    assert rel_err(o_m.state[pm]["max_exp_avg_sq"], o_r.state[pr]["max_exp_avg_sq"]) < TOL
+
+
 def test_fused_training_loop_tracks_the_oracle(cuda):
     """The epoch of flat_amazon.py:99-109 with the fused loss and optimizer vs the oracle with torch's."""
     from pytextgcn_amd.functional import masked_cross_entropy
