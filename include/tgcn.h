@@ -158,6 +158,14 @@ int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classe
                    const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
                    float *dlogits, int64_t ldd, void *workspace, size_t workspace_bytes,
                    tgcn_stream stream);
+/* tgcn_masked_ce_pred -- the same pass also writes pred[r] = argmax_c logits[r, c] (first index on
+ * ties) for EVERY row when pred != NULL: the predictions the reference takes on the host with
+ * `np.argmax(logits[mask].cpu().numpy(), axis=1)` (flat_amazon.py:111-114), so that `pred[mask]` (8
+ * bytes per row) is what crosses PCIe instead of the masked logits. */
+int tgcn_masked_ce_pred(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                        float *dlogits, int64_t ldd, int64_t *pred, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream);
 
 /* tgcn_adam_step -- one `torch.optim.Adam(..., amsgrad=...)` update of a flat fp32 tensor
  * (flat_amazon.py:89,106), torch's single-tensor formula op for op, fused into one pass.

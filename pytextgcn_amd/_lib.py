@@ -43,6 +43,8 @@ SIGNATURES = {
     "tgcn_masked_ce_workspace_bytes": (c_size_t, []),
     "tgcn_masked_ce": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
                                c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_masked_ce_pred": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_gemm_nn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p]),
     "tgcn_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -10,6 +10,7 @@
 // Both are deterministic (fixed-order two-stage reductions, no atomics).
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 
 #include "common.h"
@@ -17,46 +18,126 @@
 namespace tgcn {
 namespace {
 
-constexpr int kCeBlocks = 1024;
+constexpr int kCeBlocks = 2048;
 
-// LPR lanes cooperate on one row; a wave handles 64/LPR rows at a time.
+// LPR lanes cooperate on one row; a wave handles 64/LPR rows at a time, two such groups per loop
+// iteration (independent dependency chains: the kernel is latency-bound, not bandwidth-bound).  For
+// C <= 4 LPR (always true for C <= 256) a lane keeps its <= 4 logits in registers: one read of the row,
+// one expf per element, shared by the loss and the gradient.
 template <int LPR>
 __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ logits, int64_t ld, int C,
                                                    const int64_t *__restrict__ target,
                                                    const uint8_t *__restrict__ mask, int64_t n_rows,
                                                    float inv_count, float *__restrict__ dlogits,
-                                                   int64_t ldd, float *__restrict__ partial) {
+                                                   int64_t ldd, float *__restrict__ partial,
+                                                   int64_t *__restrict__ pred) {
     constexpr int RPW = 64 / LPR;
+    constexpr int KPL = 4;       // logits per lane on the register path
+    constexpr int UN = 2;        // row groups in flight per wave
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
-    const int64_t rows_per_iter = int64_t(gridDim.x) * 4 * RPW;
+    const int64_t rows_per_iter = int64_t(gridDim.x) * 4 * RPW * UN;
+    const bool in_regs = C <= KPL * LPR;
     float loss = 0.f;
-    for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * RPW; r0 < n_rows; r0 += rows_per_iter) {
-        const int64_t r = r0 + sub;
-        const bool valid = r < n_rows;
-        const bool on = valid && mask[r] != 0;
-        const float *row = logits + (valid ? r : 0) * ld;
-        float m = -INFINITY;
-        if (on)
-            for (int c = sl; c < C; c += LPR) m = fmaxf(m, row[c]);
+    for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * RPW * UN; r0 < n_rows; r0 += rows_per_iter) {
+        if (in_regs) {
+            float x[UN][KPL];
+            bool on[UN], valid[UN];
+            int64_t r[UN], t[UN];
 #pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        float s = 0.f;
-        if (on)
-            for (int c = sl; c < C; c += LPR) s += expf(row[c] - m);
+            for (int u = 0; u < UN; ++u) {
+                r[u] = r0 + u * RPW + sub;
+                valid[u] = r[u] < n_rows;
+                on[u] = valid[u] && mask[r[u]] != 0;
+                const float *row = logits + (valid[u] ? r[u] : 0) * ld;
+                t[u] = on[u] ? target[r[u]] : 0;
 #pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        const float lse = m + logf(s);
-        int64_t t = 0;
-        if (on) {
-            t = target[r];
-            if (sl == 0) loss += lse - row[t];
-        }
-        if (dlogits != nullptr && valid) {
-            float *drow = dlogits + r * ldd;
-            for (int c = sl; c < C; c += LPR)
-                drow[c] = on ? (expf(row[c] - lse) - (c == t ? 1.f : 0.f)) * inv_count : 0.f;
+                for (int k = 0; k < KPL; ++k) {
+                    const int c = sl + k * LPR;
+                    x[u][k] = ((on[u] || (pred != nullptr && valid[u])) && c < C) ? row[c] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                float m = fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3]));
+#pragma unroll
+                for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                if (pred != nullptr) {
+                    // arg-max of the row (first index on ties), for every row, masked or not
+                    int bi = INT32_MAX;
+#pragma unroll
+                    for (int k = KPL - 1; k >= 0; --k)
+                        if (x[u][k] == m) bi = sl + k * LPR;
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) bi = min(bi, __shfl_xor(bi, off, 64));
+                    if (valid[u] && sl == 0) pred[r[u]] = bi == INT32_MAX ? 0 : bi;
+                }
+                float e[KPL], sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    e[k] = on[u] ? expf(x[u][k] - m) : 0.f;   // exp(-inf) = 0 for the padding
+                    sum += e[k];
+                }
+#pragma unroll
+                for (int off = LPR / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                if (on[u]) {
+                    const float lse = m + logf(sum);
+                    // the lane that holds the target logit adds the row's loss term
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (sl + k * LPR == t[u]) loss += lse - x[u][k];
+                }
+                if (dlogits != nullptr && valid[u]) {
+                    float *drow = dlogits + r[u] * ldd;
+                    const float inv = on[u] ? 1.f / sum : 0.f;
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) {
+                        const int c = sl + k * LPR;
+                        if (c < C) drow[c] = on[u] ? (e[k] * inv - (c == t[u] ? 1.f : 0.f)) * inv_count : 0.f;
+                    }
+                }
+            }
+        } else {
+            for (int u = 0; u < UN; ++u) {
+                const int64_t r = r0 + u * RPW + sub;
+                const bool valid = r < n_rows;
+                const bool on = valid && mask[r] != 0;
+                const float *row = logits + (valid ? r : 0) * ld;
+                float m = -INFINITY;
+                if (on || (pred != nullptr && valid))
+                    for (int c = sl; c < C; c += LPR) m = fmaxf(m, row[c]);
+#pragma unroll
+                for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                if (pred != nullptr) {
+                    int bi = INT32_MAX;
+                    if (valid)
+                        for (int c = sl; c < C; c += LPR)
+                            if (row[c] == m) {
+                                bi = c;
+                                break;
+                            }
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) bi = min(bi, __shfl_xor(bi, off, 64));
+                    if (valid && sl == 0) pred[r] = bi == INT32_MAX ? 0 : bi;
+                }
+                float s = 0.f;
+                if (on)
+                    for (int c = sl; c < C; c += LPR) s += expf(row[c] - m);
+#pragma unroll
+                for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float lse = m + logf(s);
+                int64_t t = 0;
+                if (on) {
+                    t = target[r];
+                    if (sl == 0) loss += lse - row[t];
+                }
+                if (dlogits != nullptr && valid) {
+                    float *drow = dlogits + r * ldd;
+                    for (int c = sl; c < C; c += LPR)
+                        drow[c] = on ? (expf(row[c] - lse) - (c == t ? 1.f : 0.f)) * inv_count : 0.f;
+                }
+            }
         }
     }
 #pragma unroll
@@ -191,6 +272,14 @@ int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classe
                    const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
                    float *dlogits, int64_t ldd, void *workspace, size_t workspace_bytes,
                    tgcn_stream stream) {
+    return tgcn_masked_ce_pred(logits, ld, n_rows, n_classes, target, mask, inv_count, loss, dlogits, ldd,
+                               nullptr, workspace, workspace_bytes, stream);
+}
+
+int tgcn_masked_ce_pred(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                        float *dlogits, int64_t ldd, int64_t *pred, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream) {
     using namespace tgcn;
     if (!logits || !target || !mask || !loss || n_rows < 0 || n_classes <= 0 || ld < n_classes ||
         (dlogits && ldd < n_classes)) {
@@ -205,18 +294,18 @@ int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classe
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *partial = static_cast<float *>(workspace);
-    int64_t rows_per_block = 4 * (n_classes <= 16 ? 16 : n_classes <= 32 ? 8 : n_classes <= 64 ? 4 : n_classes <= 128 ? 2 : 1);
+    int64_t rows_per_block = 2 * 4 * (n_classes <= 16 ? 16 : n_classes <= 32 ? 8 : n_classes <= 64 ? 4 : n_classes <= 128 ? 2 : 1);
     int grid = static_cast<int>(std::min<int64_t>(kCeBlocks, std::max<int64_t>(1, (n_rows + rows_per_block - 1) / rows_per_block)));
     if (n_classes <= 16)
-        k_masked_ce<4><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+        k_masked_ce<4><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
     else if (n_classes <= 32)
-        k_masked_ce<8><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+        k_masked_ce<8><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
     else if (n_classes <= 64)
-        k_masked_ce<16><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+        k_masked_ce<16><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
     else if (n_classes <= 128)
-        k_masked_ce<32><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+        k_masked_ce<32><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
     else
-        k_masked_ce<64><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial);
+        k_masked_ce<64><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
     TGCN_HIP_CHECK(hipGetLastError());
     k_ce_final<<<1, 256, 0, s>>>(partial, grid, inv_count, loss);
     TGCN_HIP_CHECK(hipGetLastError());

@@ -20,17 +20,24 @@ _COUNT_CACHE: dict = {}
 
 
 def _mask_count(mask: Tensor) -> int:
-    """Rows selected by a (static) mask; one device sync per distinct mask version."""
-    key = (mask.data_ptr(), mask._version, mask.numel(), mask.device)
+    """Rows selected by a (static) mask; one device sync per distinct mask OBJECT and version.  Keyed
+    by id() and validated through a weak reference: a data pointer is no identity (the allocator hands
+    the storage of a dead temporary to the next one)."""
+    import weakref
+    key = id(mask)
     hit = _COUNT_CACHE.get(key)
-    if hit is None:
-        if len(_COUNT_CACHE) > 64:
-            _COUNT_CACHE.clear()
-        hit = _COUNT_CACHE[key] = int(mask.sum().item())
-    return hit
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+        return hit[2]
+    count = int(mask.sum().item())
+    try:
+        ref = weakref.ref(mask, lambda _, k=key: _COUNT_CACHE.pop(k, None))
+    except TypeError:
+        return count
+    _COUNT_CACHE[key] = (ref, mask._version, count)
+    return count
 
 
-def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count=None):
+def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count=None, want_pred: bool = False):
     lib = _lib.load()
     _require_cuda(logits, "logits")
     if logits.dtype != torch.float32 or logits.dim() != 2:
@@ -49,32 +56,40 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count
     inv = 1.0 / count if count else float("nan")          # torch: mean over an empty selection = nan
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device) if want_grad else None
+    pred = torch.empty(n, dtype=torch.int64, device=logits.device) if want_pred else None
     ws_bytes = lib.tgcn_masked_ce_workspace_bytes()
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
-    _lib.check(lib.tgcn_masked_ce(
+    _lib.check(lib.tgcn_masked_ce_pred(
         logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(), mask.data_ptr(),
         ctypes.c_float(inv), loss.data_ptr(),
         dlogits.data_ptr() if dlogits is not None else None, C,
+        pred.data_ptr() if pred is not None else None,
         ws.data_ptr(), ws_bytes, _stream_ptr(logits.device)))
-    return loss, dlogits
+    return loss, dlogits, pred
 
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count):
-        loss, dlogits = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count)
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count, want_pred: bool):
+        loss, dlogits, pred = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count, want_pred)
         ctx.save_for_backward(dlogits)
-        return loss
+        if not want_pred:
+            return loss
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
 
     @staticmethod
-    def backward(ctx, grad_out: Tensor):
+    def backward(ctx, grad_out: Tensor, *_):
         (dlogits,) = ctx.saved_tensors
-        return dlogits.mul_(grad_out), None, None, None    # dlogits is ours: scale in place
+        return dlogits.mul_(grad_out), None, None, None, None    # dlogits is ours: scale in place
 
 
-def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor, count=None) -> Tensor:
+def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor, count=None, return_pred: bool = False):
     """`count` overrides the divisor (default: rows selected by `mask`); the sharded path passes the
-    GLOBAL count so that per-rank losses and gradients add up to the single-device ones."""
+    GLOBAL count so that per-rank losses and gradients add up to the single-device ones.
+    `return_pred=True` returns `(loss, pred)` with `pred = logits.argmax(1)` for EVERY row, taken in the
+    same pass: `pred[mask]` is what the reference computes on the host at flat_amazon.py:111-114."""
     if logits.requires_grad and torch.is_grad_enabled():
-        return _MaskedCE.apply(logits, target, mask, count)
-    return _launch(logits, target, mask, False, count)[0]
+        return _MaskedCE.apply(logits, target, mask, count, return_pred)
+    loss, _, pred = _launch(logits, target, mask, False, count, return_pred)
+    return (loss, pred) if return_pred else loss

@@ -336,15 +336,19 @@ def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tenso
     local sum of row losses divided by the global row count, so that summing the replicated
     gradients over ranks reproduces the single-device gradient.  Returns this rank's share of the
     loss; all-reduce it (sum) for the value the reference prints."""
-    key = (mask_local.data_ptr(), mask_local._version)
-    cached = getattr(sg, "_count_cache", {}).get(key)
-    if cached is None:                                   # masks are static: count (and sync) once
+    # masks are static: count (and sync) once per mask object / version; the entry holds the tensor, so
+    # its id() cannot be recycled while the entry lives
+    cache = sg.__dict__.setdefault("_count_cache", {})
+    hit = cache.get(id(mask_local))
+    if hit is not None and hit[0] is mask_local and hit[1] == mask_local._version:
+        cached = hit[2]
+    else:
         c = mask_local.sum().to(torch.float64).reshape(1)
         dist.all_reduce(c, group=sg.group)
         cached = int(c.item())
-        if not hasattr(sg, "_count_cache"):
-            sg._count_cache = {}
-        sg._count_cache[key] = cached
+        if len(cache) > 16:
+            cache.clear()
+        cache[id(mask_local)] = (mask_local, mask_local._version, cached)
     if hasattr(sg.engine, "masked_ce"):                  # fused HIP kernel, global divisor
         return sg.engine.masked_ce(logits_local, y_local, mask_local, cached)
     cnt = torch.tensor(float(cached), device=logits_local.device)

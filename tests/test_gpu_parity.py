@@ -400,6 +400,31 @@ def test_fused_adam_matches_torch(cuda, amsgrad, wd):
     assert rel_err(st["exp_avg_sq"], o_r.state[ref_p[0]]["exp_avg_sq"]) < TOL
 
 
+@pytest.mark.parametrize("n,C", [(5000, 64), (777, 7), (300, 300), (2000, 129)])
+def test_masked_cross_entropy_predictions(cuda, n, C):
+    """return_pred=True: arg-max of EVERY row (first index on ties, as torch on the CPU), in the same pass;
+    loss and gradient unchanged."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    gen = torch.Generator().manual_seed(n + C)
+    logits = torch.randn(n, C, generator=gen)
+    logits[::7] = torch.round(logits[::7])                       # plenty of ties
+    logits[5] = 0.0
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.3
+    ld = logits.to(cuda).requires_grad_()
+    loss, pred = masked_cross_entropy(ld, y.to(cuda), mask.to(cuda), return_pred=True)
+    loss.backward()
+    assert pred.dtype == torch.int64 and torch.equal(pred.cpu(), logits.argmax(1))
+    lr = logits.clone().requires_grad_()
+    want = torch.nn.functional.cross_entropy(lr[mask], y[mask])
+    want.backward()
+    assert abs(loss.item() - want.item()) < TOL * abs(want.item())
+    assert rel_err(ld.grad, lr.grad) < TOL
+    with torch.no_grad():
+        l2, p2 = masked_cross_entropy(ld.detach(), y.to(cuda), mask.to(cuda), return_pred=True)
+    assert torch.equal(p2, pred) and abs(l2.item() - want.item()) < TOL * abs(want.item())
+
+
 def test_fused_adam_streaming_path_for_large_tensors(cuda):
     """>= 2^24 elements take the non-temporal (streaming) form of k_adam: same numbers as torch's Adam
     on the device, including the ragged tail."""

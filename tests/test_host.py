@@ -138,3 +138,18 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(d["value"] - 2 * 50_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "edges/s" and c["sample"]
+
+
+def test_mask_count_cache_is_keyed_by_object_not_by_address():
+    """A dead temporary's storage (and id) can be handed to the next mask: the cached row count must not
+    follow it."""
+    from pytextgcn_amd.functional import _mask_count
+    for k in range(1, 40):
+        m = torch.zeros(64, dtype=torch.bool)
+        m[:k] = True
+        assert _mask_count(m) == k
+        del m
+    keep = torch.ones(10, dtype=torch.bool)
+    assert _mask_count(keep) == 10 and _mask_count(keep) == 10
+    keep[0] = False                                   # in-place edit bumps the version
+    assert _mask_count(keep) == 9
