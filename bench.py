@@ -83,6 +83,23 @@ def cpu_baseline(plan, F, frac, seed=44):
                       f"{t:.2f} s per fwd+bwd pair, os.cpu_count()={os.cpu_count()}"}
 
 
+def device_copy_gbps(dev, n_bytes=1 << 30, reps=10):
+    """Secondary roofline denominator: what this box's HBM delivers to a plain
+    device-to-device copy, read + written bytes per second."""
+    a = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        b.copy_(a)
+    ev[1].record()
+    torch.cuda.synchronize()
+    return 2.0 * n_bytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+
+
 def measured_traffic(config, n_gpus):
     """HBM bytes per SpMM launch from rocprofv3 PMC passes (profiles/traffic.json, collected and
     corrected as MI355X_MICROARCH.md 'HBM' prescribes); None when no measurement is on file."""
@@ -331,6 +348,7 @@ def main():
         epoch_ms_reuse = epoch_time_ms(g, F, C, fused=True, reuse=True)
         epoch_ms_collapse = epoch_time_ms(g, F, C, fused=True, collapse=True)
 
+    copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -353,6 +371,8 @@ def main():
                          "traffic": measured_traffic(args.config, world),
                          "kernel": "one tgcn_spmm launch: k_spmm_gather (+ k_spmm_hot, k_spmm_fix)" if parallelism == "single"
                                    else "one distributed SpMM on this rank: local k_spmm_gather launches + RCCL all-gather / reduce-scatter",
+                         # secondary denominator: this box's device-to-device copy rate (read + write)
+                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
                          "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
                          "algorithmic_bytes_per_launch": launch_bytes},
             "epoch_ms": epoch_ms,
