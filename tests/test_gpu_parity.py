@@ -1067,3 +1067,24 @@ def test_graphed_training_with_fused_dropout_draws_a_new_mask_per_replay(cuda):
         pkg.enable_fused_dropout(False)
     assert len(set(losses)) == 5 and all(np.isfinite(losses))
     assert max(losses) - min(losses) < 0.2 * abs(losses[0])          # same weights, different masks
+
+
+@pytest.mark.parametrize("order,weight,col_block,ratio", [(4, 128, 256, 0.5), (0, 2048, 0, 1.0), (2, 512, 100000, 3.0)])
+def test_dense_hot_block_with_other_partition_knobs(cuda, monkeypatch, order, weight, col_block, ratio):
+    """The hot block next to every launch order / item weight / column-block setting of build_items."""
+    monkeypatch.setenv("TGCN_ITEM_ORDER", str(order))
+    monkeypatch.setenv("TGCN_ITEM_WEIGHT", str(weight))
+    monkeypatch.setenv("TGCN_COL_BLOCK", str(col_block))
+    monkeypatch.setenv("TGCN_HOT_RATIO", str(ratio))
+    n = 6007
+    gen = torch.Generator().manual_seed(order + weight)
+    ei, w = _hub_graph(n, 36, gen, dup=True)
+    plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    assert plan.stats()["hot_rows"] > 0
+    for F in (200, 64, 7):
+        x = torch.randn(n, F, generator=gen)
+        b = torch.randn(F, generator=gen)
+        for transpose in (False, True):
+            ref = oracle_spmm(ei, w, n, x, b, transpose=transpose)
+            assert rel_err(plan.spmm(x.to(cuda), b.to(cuda), transpose=transpose), ref) < TOL, (F, transpose)
+    plan.close()
