@@ -64,7 +64,7 @@ def _encode_input(X: List[str], n_jobs, vocabulary: Dict[str, int], verbose, n_d
     """text2graph.py:20-46: `\\w+` tokens, lower-cased, in-vocabulary only, cut to max_len, padded
     with -1 to the longest document; int32 [n_docs, max_sent_len]."""
     if verbose > 0:
-        print("Tokenizing text and removing unwanted words...")
+        print("text2graph: tokenising (\\w+, lower case, in-vocabulary words only)")
     sl = slice(None) if max_len is None else slice(max_len)
 
     def encode(chunk):
@@ -80,7 +80,7 @@ def _encode_input(X: List[str], n_jobs, vocabulary: Dict[str, int], verbose, n_d
         docs = encode(X)
     max_sent_len = max(map(len, docs)) if docs else 0
     if verbose > 1:
-        print(f"Sequence length is {max_sent_len}")
+        print(f"text2graph: longest document has {max_sent_len} tokens")
     out = np.full((len(docs), max(max_sent_len, 1)), -1, dtype=np.int32)
     for i, d in enumerate(docs):
         out[i, :len(d)] = d
@@ -92,21 +92,17 @@ class Text2GraphTransformer(BaseEstimator, TransformerMixin):
     def __init__(self, min_df: Union[int, float] = 5, window_size: int = 20, save_path: str = None,
                  n_jobs: int = 1, max_df=1.0, verbose=0, rm_stopwords=True, sparse_features=True,
                  max_length: Optional[int] = None):
-        self.max_length = max_length
-        self.sparse_features = sparse_features
-        self.rm_stopwords = rm_stopwords
-        self.verbose = verbose
-        self.max_df = max_df
-        self.n_jobs = n_jobs
-        assert min_df > 0
-        self.min_df = min_df
-        self.save_path = save_path
-        self.input = None
-        self.cv = None
-        self.window_size = window_size
-        self.stop_words = None
-        if self.rm_stopwords:
-            self.stop_words = _english_stopwords()
+        assert min_df > 0                      # same failure mode as the reference (text2graph.py:77)
+        # sklearn estimator convention: one attribute per constructor argument, same name
+        self.min_df, self.window_size, self.save_path = min_df, window_size, save_path
+        self.n_jobs, self.max_df, self.verbose = n_jobs, max_df, verbose
+        self.rm_stopwords, self.sparse_features, self.max_length = rm_stopwords, sparse_features, max_length
+        self.input, self.cv = None, None
+        self.stop_words = _english_stopwords() if rm_stopwords else None
+
+    def _say(self, level: int, msg: str) -> None:
+        if self.verbose > level:
+            print("text2graph: " + msg)
 
     def fit_transform(self, X: Union[List[str], str], y=None, test_idx=None, val_idx=None,
                       hierarchy_feats: Union[th.Tensor, None] = None) -> Data:
@@ -117,28 +113,21 @@ class Text2GraphTransformer(BaseEstimator, TransformerMixin):
         test_idx = th.as_tensor([] if test_idx is None else test_idx, dtype=th.long)
         if y is not None:
             y = th.as_tensor(y, dtype=th.long)
-        if isinstance(X, list):
-            self.input = X
-        else:
-            if self.verbose > 0:
-                print(f"Loading input from {X}")
-            self.input = []
-            for f in glob.glob(os.path.join(X, "*.txt")):
-                with open(f, "r") as fp:
-                    self.input.append(fp.read())
+        if not isinstance(X, list):                 # a directory of *.txt files (text2graph.py:110-117)
+            self._say(0, f"reading *.txt under {X}")
+            paths = glob.glob(os.path.join(X, "*.txt"))
+            X = [open(path, "r").read() for path in paths]
+        self.input = X
         stop = None if self.stop_words is None else sorted(self.stop_words)
         self.cv = CountVectorizer(stop_words=stop, min_df=self.min_df, max_df=self.max_df)
         occ = self.cv.fit_transform(self.input).tocsr()                       # stays sparse
         occ.sort_indices()
         n_docs, n_vocabs = occ.shape
-        if self.verbose > 1:
-            print(f"Number of documents in input: {n_docs}")
-            print(f"Vocabulary size: {n_vocabs}")
+        self._say(1, f"{n_docs} documents, vocabulary of {n_vocabs} words")
         self.n_docs_, self.n_vocabs_, self.n_nodes_ = n_docs, n_vocabs, n_docs + n_vocabs
         tokens, self.max_sent_len_ = _encode_input(self.input, self.n_jobs, self.cv.vocabulary_,
                                                    self.verbose, n_docs, self.max_length)
-        if self.verbose > 0:
-            print("Building doc-word edges...")
+        self._say(0, "document-word edges (TF-IDF)")
         tfidf = TfidfTransformer().fit_transform(occ).tocsr()
         tfidf.sort_indices()
         # th.nonzero of the dense matrix (text2graph.py:148) = CSR order with sorted column indices
@@ -148,8 +137,7 @@ class Text2GraphTransformer(BaseEstimator, TransformerMixin):
             dw_weight = tfidf.data
         else:                                                                  # explicit zeros etc.
             dw_weight = np.asarray(tfidf[doc_ids, word_ids]).ravel()
-        if self.verbose > 0:
-            print("Building word-word edges...")
+        self._say(0, "word-word edges (PMI over sliding windows)")
         ww_coo, ww_w = graphbuilder.compute_word_word_edges(tokens, n_vocabs, n_docs, self.max_sent_len_,
                                                             self.window_size, self.n_jobs, self.verbose)
         n_ww, n_dw = ww_coo.shape[0], doc_ids.shape[0]
@@ -159,15 +147,17 @@ class Text2GraphTransformer(BaseEstimator, TransformerMixin):
         coo[n_ww + n_dw:, 0], coo[n_ww + n_dw:, 1] = word_ids, doc_ids + n_vocabs           # word -> doc
         dw32 = dw_weight.astype(np.float32)                                    # f64 -> f32 as `.float()` at :192
         edge_weights = np.concatenate([ww_w, dw32, dw32])
-        if self.verbose > 0:
-            print(f"total edge shape is {coo.shape}")
+        self._say(0, f"{coo.shape[0]} directed edges in total")
         feats = self.node_feats(hierarchy_feats) if self.sparse_features else th.eye(self.n_nodes_)
-        test_mask = th.zeros(self.n_nodes_, dtype=th.bool)
-        val_mask = th.zeros(self.n_nodes_, dtype=th.bool)
-        test_mask[test_idx + n_vocabs] = True
-        if val_idx is not None:
-            val_mask[th.as_tensor(val_idx, dtype=th.long) + n_vocabs] = True
-        train_mask = th.logical_not(th.logical_or(test_mask, val_mask))
+        # masks over all nodes: documents listed in test_idx / val_idx, every other DOCUMENT trains,
+        # word nodes belong to no split (text2graph.py:180-188)
+        def doc_mask(idx):
+            m = th.zeros(self.n_nodes_, dtype=th.bool)
+            if idx is not None:
+                m[th.as_tensor(idx, dtype=th.long) + n_vocabs] = True
+            return m
+        test_mask, val_mask = doc_mask(test_idx), doc_mask(val_idx)
+        train_mask = ~(test_mask | val_mask)
         train_mask[:n_vocabs] = False
         y_nodes = th.zeros(self.n_nodes_, dtype=th.long)        # pseudo label 0 on word nodes
         if y is not None:
@@ -175,20 +165,20 @@ class Text2GraphTransformer(BaseEstimator, TransformerMixin):
         g = Data(x=feats.float(), edge_index=th.from_numpy(coo).T, edge_attr=th.from_numpy(edge_weights),
                  y=y_nodes, test_mask=test_mask, train_mask=train_mask, val_mask=val_mask,
                  n_vocab=n_vocabs)
-        if self.save_path is not None:
-            print(f"saving to  {self.save_path}")
+        if self.save_path is not None:              # pickle next to the reference's naming (text2graph.py:195-204)
             os.makedirs(self.save_path, exist_ok=True)
-            with open(os.path.join(self.save_path, f"TGData_{time.time()}.p"), "wb") as fp:
-                pickle.dump(g, fp)
-            print("save successful!")
+            target = os.path.join(self.save_path, f"TGData_{time.time()}.p")
+            with open(target, "wb") as out:
+                pickle.dump(g, out)
+            print(f"text2graph: graph pickled to {target}")
         return g
 
     @staticmethod
     def load_graph(save_path):
         if not os.path.exists(save_path):
-            raise FileNotFoundError("Given file does not exist!")
-        with open(save_path, "rb") as fp:
-            return pickle.load(fp)
+            raise FileNotFoundError(f"no pickled graph at {save_path}")
+        with open(save_path, "rb") as src:
+            return pickle.load(src)
 
     @property
     def vocabulary(self) -> Dict[str, int]:
