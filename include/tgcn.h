@@ -123,6 +123,10 @@ int tgcn_plan_export(const tgcn_plan *plan, int transpose, int32_t *rowptr /* n_
  *   bias [F] or NULL
  * Fast path: F, ldx, ldy multiples of 4 and X, Y, bias 16-byte aligned; anything else takes the
  * scalar-lane kernel (same results).  Nothing of size nnz x F is ever written.
+ * Plans of graphs whose 32 longest rows are nearly dense (TGCN_Q_HOT_ROWS > 0) compute those rows as a
+ * dense product over all columns: with a non-finite value in X[c] they become non-finite even where
+ * M[row, c] == 0 (0 * inf).  Finite operands give the reference's result; TGCN_HOT_ROWS=0 in the
+ * environment at plan creation disables the dense block.
  */
 size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F);
 int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, int F,
