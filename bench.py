@@ -213,6 +213,54 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3):
     return t.item()
 
 
+def exchange_diagnostics(sg, F, dev, dist, reps=10):
+    """N > 1 only, outside the timed region: where one distributed SpMM spends its time on THIS node.
+    Every phase is timed on its own (barrier + sync on both sides, max over ranks): the two local
+    operators, the two RCCL collectives of pytextgcn_amd.sharded, and an all-to-all formulation of the
+    reduce-scatter (all_to_all_single + local sum) for comparison.  A phase that raises is reported as
+    null; nothing here feeds `value`."""
+    A, B = sg.ops[0]
+    W, hp, rp = sg.world, sg.hp, sg.rp
+    gen = torch.Generator(device=dev).manual_seed(99)
+    x = torch.randn(sg.n_local, F, device=dev, generator=gen)
+    xbuf = torch.empty(W * hp, F, device=dev)
+    partial = torch.randn(W * hp, F, device=dev, generator=gen)
+    rs_out = torch.empty(hp, F, device=dev)
+    a2a = torch.empty(W * hp, F, device=dev)
+
+    def phase(fn):
+        try:
+            for _ in range(2):
+                fn()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], device=dev, dtype=torch.float64)
+            lo = dt.clone()
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            return {"max_ms": round(dt.item(), 4), "min_ms": round(lo.item(), 4)}
+        except Exception as e:                       # noqa: BLE001 - diagnostics must never sink the bench line
+            return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+    out = {"bytes_each_way_per_collective": int((W - 1) * hp * F * 4)}
+    if A is not None:
+        out["local_A_hub_rows_x_own_regulars"] = phase(lambda: A.spmm(x[hp:]))
+    out["local_B_own_rows"] = phase(lambda: B.spmm(xbuf, None, x2=x[hp:] if rp > 0 else None))
+    out["all_gather_into_tensor"] = phase(lambda: dist.all_gather_into_tensor(xbuf, x[:hp].contiguous()))
+    out["reduce_scatter_tensor"] = phase(lambda: dist.reduce_scatter_tensor(rs_out, partial))
+
+    def rs_by_all_to_all():
+        dist.all_to_all_single(a2a, partial)
+        torch.sum(a2a.view(W, hp, F), dim=0, out=rs_out)
+    out["reduce_scatter_as_all_to_all_plus_sum"] = phase(rs_by_all_to_all)
+    out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -341,6 +389,7 @@ def main():
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
+    diagnostics = exchange_diagnostics(sg, F, dev, dist) if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = epoch_time_ms(g, F, C, fused=False)
@@ -383,6 +432,8 @@ def main():
             # NOT part of the metric either: pytextgcn_amd.enable_linear_collapse() evaluates the eval forward of
             # the activation-free network (models.py:22) as two propagations at the class width
             "epoch_ms_fused_with_collapsed_eval": epoch_ms_collapse,
+            # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
+            "exchange_diagnostics": diagnostics,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac)
