@@ -270,6 +270,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # a checkout without binaries (the .so is git-ignored): local rank 0 compiles it once (hipcc is on the
+    # GPU box, os.replace makes the file appear atomically), the other ranks wait for the file
+    from pytextgcn_amd import build as _build
+    if not os.path.exists(_build.LIB_PATH):
+        if local_rank == 0:
+            _build.build()
+        else:
+            for _ in range(1800):
+                if os.path.exists(_build.LIB_PATH):
+                    break
+                time.sleep(0.5)
     # rehearsal knobs (one-GPU box): all ranks on one card over gloo exercises the N>1 code path
     backend = os.environ.get("TGCN_BENCH_BACKEND", "nccl")
     if "TGCN_BENCH_DEVICE" in os.environ:
