@@ -168,7 +168,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
     return sorted(times)[len(times) // 2]
 
 
-def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3):
+def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
     summed with one all-reduce; predictions of the owned rows go to the host."""
@@ -182,6 +182,7 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3):
     train_l = sg.scatter_rows(is_doc & (u < 0.8))
     val_l = sg.scatter_rows(is_doc & (u >= 0.8) & (u < 0.9))
     del y_full, u
+    pkg.enable_activation_reuse(reuse)
     model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5).to(dev)
     with torch.no_grad():
         model.weights[0].uniform_(-0.0017, 0.0017)            # glorot bound of an N x h matrix
@@ -208,6 +209,8 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3):
         torch.cuda.synchronize()
         if rep:
             times.append((time.perf_counter() - t0) * 1e3)
+    pkg.enable_activation_reuse(False)
+    del model, opt
     t = torch.tensor([sorted(times)[len(times) // 2]], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
@@ -400,6 +403,7 @@ def main():
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
+        epoch_ms_reuse = sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True)
     diagnostics = exchange_diagnostics(sg, F, dev, dist) if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout

@@ -136,6 +136,44 @@ def check(kind, device="cpu"):
     for k, v in ref.state_dict().items():
         assert rel_err(sd[k], v) < 1e-3, k
 
+    # opt-in activation reuse: eval forward, then a training forward on the same weights re-uses layer 1
+    # (one distributed SpMM less), bitwise the same logits and gradients; an optimizer step invalidates
+    import pytextgcn_amd as pkg
+    calls = {"n": 0}
+    real_spmm = sg.spmm
+
+    def counting_spmm(*a, **kw):
+        calls["n"] += 1
+        return real_spmm(*a, **kw)
+    sg.spmm = counting_spmm
+    try:
+        def fwd_bwd():
+            mine.train()
+            out = mine()
+            loss = sharded.sharded_cross_entropy(sg, out, y_l, m_l)
+            o_m.zero_grad(set_to_none=True)
+            loss.backward()
+            return out.detach().clone(), mine.weights[0].grad.clone()
+        plain_out, plain_g = fwd_bwd()
+        pkg.enable_activation_reuse(True)
+        mine.eval()
+        with torch.no_grad():
+            ev = mine()
+        calls["n"] = 0
+        out, g1 = fwd_bwd()
+        assert calls["n"] == 3 + 3 - 1, calls              # 3 layers forward + 3 backward, layer-1 forward re-used
+        assert torch.equal(out, plain_out) and torch.equal(g1, plain_g)
+        mine.sync_grads()
+        o_m.step()                                           # bumps the version counters
+        calls["n"] = 0
+        mine.eval()
+        with torch.no_grad():
+            ev2 = mine()
+        assert calls["n"] == 3 and not torch.equal(ev2, ev)
+    finally:
+        pkg.enable_activation_reuse(False)
+        sg.spmm = real_spmm
+
 
 def check_hip(kind, g, hubs, N, dev):
     """The same checks with the product engine (libtgcn.so) on a GPU; all ranks may share one card
