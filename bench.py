@@ -201,9 +201,9 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
         model.eval()
         with torch.no_grad():
             logits = model()
-            sharded_cross_entropy(sg, logits, y_l, val_l)
-            pred_val = logits[val_l].argmax(1).cpu().numpy()
-            pred_train = logits[train_l].argmax(1).cpu().numpy()
+            _, pred = sharded_cross_entropy(sg, logits, y_l, val_l, return_pred=True)
+            pred_val = pred[val_l].cpu().numpy()
+            pred_train = pred[train_l].cpu().numpy()
         loss.item()
         dist.barrier()
         torch.cuda.synchronize()

@@ -70,9 +70,9 @@ class HipEngine:
         from . import dense
         return dense.xw_dropout(x, w, p)      # dropout fused into the three GEMMs (mask never stored)
 
-    def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int) -> Tensor:
+    def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int, return_pred: bool = False):
         from .functional import masked_cross_entropy
-        return masked_cross_entropy(logits, y, mask, count=count)
+        return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
 
 
 class Partition:
@@ -366,11 +366,12 @@ class ShardedGCN(nn.Module):
 
 
 def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tensor,
-                          mask_local: Tensor) -> Tensor:
+                          mask_local: Tensor, return_pred: bool = False):
     """CrossEntropyLoss(reduction='mean') over the GLOBAL masked rows (flat_amazon.py:82,101-102):
     local sum of row losses divided by the global row count, so that summing the replicated
     gradients over ranks reproduces the single-device gradient.  Returns this rank's share of the
-    loss; all-reduce it (sum) for the value the reference prints."""
+    loss; all-reduce it (sum) for the value the reference prints.  `return_pred=True` adds the arg-max
+    of every local row (same pass on the HIP engine)."""
     # masks are static: count (and sync) once per mask object / version; the entry holds the tensor, so
     # its id() cannot be recycled while the entry lives
     cache = sg.__dict__.setdefault("_count_cache", {})
@@ -385,10 +386,10 @@ def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tenso
             cache.clear()
         cache[id(mask_local)] = (mask_local, mask_local._version, cached)
     if hasattr(sg.engine, "masked_ce"):                  # fused HIP kernel, global divisor
-        return sg.engine.masked_ce(logits_local, y_local, mask_local, cached)
+        return sg.engine.masked_ce(logits_local, y_local, mask_local, cached, return_pred)
     cnt = torch.tensor(float(cached), device=logits_local.device)
     if bool(mask_local.any()):
         part = nn.functional.cross_entropy(logits_local[mask_local], y_local[mask_local], reduction="sum")
     else:
         part = logits_local.sum() * 0.0
-    return part / cnt
+    return (part / cnt, logits_local.argmax(1)) if return_pred else part / cnt
