@@ -393,7 +393,8 @@ def main():
         ops_b = [op for op in sg.ops[-1] if op is not None]
         bytes_fwd = sum(op.algorithmic_bytes(F) for op in ops_f) + 4 * F
         bytes_bwd = sum(op.algorithmic_bytes(F) for op in ops_b)
-        parallelism = f"row{world}: hubs(words) replicated by all-gather, hub rows reduce-scattered"
+        parallelism = (f"row{world}: hubs(words) replicated by all-gather, hub rows reduce-scattered"
+                       f" (exchange={sg.exchange})")
 
     def barrier():
         if dist is not None:

@@ -157,6 +157,13 @@ class ShardedGraph:
             self.ops.append(self._local_ops(row, col, val))
         del row, col, val
         self.plan = self.ops[0][1]            # the larger local operator (for reporting)
+        # "collective": RCCL all-gather + reduce-scatter (default).  "p2p": the same exchange as direct
+        # pairwise transfers (batched send/recv, all-to-all + local sum) -- on a full xGMI mesh every pair
+        # has its own link; kept selectable (TGCN_EXCHANGE) until 8-GPU timings say which is faster.
+        import os
+        self.exchange = os.environ.get("TGCN_EXCHANGE", "collective")
+        if self.exchange not in ("collective", "p2p"):
+            raise ValueError("TGCN_EXCHANGE must be 'collective' or 'p2p'")
         self._xbuf = {}
 
     @classmethod
@@ -222,21 +229,43 @@ class ShardedGraph:
             self._xbuf = {key: xbuf}
         if hp == 0:
             raise ValueError("a sharded graph needs at least one hub node per rank")
-        ag = dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)
+        p2p = self.exchange == "p2p"
+        ag = self._all_gather_p2p(xbuf, x_local[:hp]) if p2p else \
+            [dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)]
         rs = rs_out = None
         if A is not None:
             partial = A.spmm(x_local[hp:])                       # overlaps the all-gather
-            ag.wait()
-            rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
-            rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
+            for w in ag:
+                w.wait()
+            if p2p:
+                # reduce-scatter as an all-to-all of the W slices (every pair of GPUs talks over its own
+                # xGMI link at the same time) + a local sum in rank order
+                rs_out = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
+                rs = dist.all_to_all_single(rs_out, partial, group=self.group, async_op=True)
+            else:
+                rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
+                rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
         else:
-            ag.wait()
+            for w in ag:
+                w.wait()
         # split operand: hub columns from the gathered block, own regular columns straight from x_local
         y = B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)   # overlaps the reduce-scatter
         if rs is not None:
             rs.wait()
-            y[:hp] += rs_out
+            y[:hp] += rs_out.view(W, hp, F).sum(0) if p2p else rs_out
         return y
+
+    def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):
+        """All-gather as W - 1 direct sends and receives per rank, batched into one group call."""
+        hp = self.hp
+        ranks = dist.get_process_group_ranks(self.group)
+        ops = []
+        for q in range(self.world):
+            if q != self.rank:
+                ops.append(dist.P2POp(dist.isend, shard, ranks[q], group=self.group))
+                ops.append(dist.P2POp(dist.irecv, xbuf[q * hp:(q + 1) * hp], ranks[q], group=self.group))
+        xbuf[self.rank * hp:(self.rank + 1) * hp].copy_(shard)
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def colsum_real(self, g_local: Tensor) -> Tensor:
         """Column sums over this rank's real rows (padding rows carry zero gradient by

@@ -66,3 +66,9 @@ def test_world3_asymmetric_graph_and_uneven_shards():
 
 def test_world4_hub_partition():
     run(4, ["wordoc"])
+
+
+def test_world3_pairwise_exchange(monkeypatch):
+    """TGCN_EXCHANGE=p2p: the same hub exchange as batched send/recv + all-to-all with a local sum."""
+    monkeypatch.setenv("TGCN_EXCHANGE", "p2p")            # inherited by the spawned ranks
+    run(3, ["wordoc", "asym"])
