@@ -13,7 +13,8 @@ from pytextgcn_amd import synth  # noqa: E402
 from pytextgcn_amd.plan import GraphPlan  # noqa: E402
 from tools.sweep_spmm import time_spmm  # noqa: E402
 
-N, E, F = 2_000_000, 50_000_000, 200
+N, E = 2_000_000, 50_000_000
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 200      # python tools/ceiling_spmm.py [F]
 g = synth.word_doc_graph(N, E, seed=44, device="cuda:0", features="none")
 plan = GraphPlan(g.edge_index, g.edge_attr, N)
 rp, col, val = plan.export_csr()
