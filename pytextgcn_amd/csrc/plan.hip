@@ -413,7 +413,21 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             }
         }
     }
-    const int32_t n_hot = static_cast<int32_t>(hot_rows.size());
+    int32_t n_hot = static_cast<int32_t>(hot_rows.size());
+    if (n_hot > 0) {
+        // the value block is an optimisation: when its memory cannot be had (n_cols x 128 bytes), the
+        // plan is built without it rather than failing
+        const int64_t cpw0 = std::max<int64_t>(64, ((b.n_cols + 256 * 8 - 1) / (256 * 8) + 7) & ~int64_t(7));
+        const size_t want = sizeof(float) * static_cast<size_t>((b.n_cols + cpw0 * 8 - 1) / (cpw0 * 8)) *
+                            static_cast<size_t>(cpw0 * 8) * kHotRows;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want + (size_t(1) << 30) > free_b) {
+            (void)hipGetLastError();
+            n_hot = 0;
+            hot_rows.clear();
+            std::fill(hot_of_long.begin(), hot_of_long.end(), -1);
+        }
+    }
     if (n_hot > 0) {
         // every wave of the hot kernel streams `cpw` consecutive columns, 8 waves per
         // workgroup, at most 256 workgroups; the value block is padded to the full grid with zeros
