@@ -32,3 +32,9 @@ def test_two_gloo_ranks_on_one_gpu_hub_partition(cuda):
 
 def test_single_rank_rccl_group(cuda):
     run(1, ["wordoc_big"], "nccl")
+
+
+def test_four_gloo_ranks_pairwise_exchange(cuda, monkeypatch):
+    """World 4 with TGCN_EXCHANGE=p2p (batched send/recv + all-to-all) and the HIP engine."""
+    monkeypatch.setenv("TGCN_EXCHANGE", "p2p")
+    run(4, ["wordoc_big"], "gloo")
