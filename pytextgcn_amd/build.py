@@ -19,35 +19,63 @@ SOURCES = ["spmm.hip", "colsum.hip", "train.hip", "dense.hip", "plan.hip", "grap
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(_ROOT, "include", "tgcn.h")]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+
+
+def _newer(path: str, deps) -> bool:
+    """True when `path` is missing or older than one of `deps`."""
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(path)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _stale() -> bool:
+    return _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile if sources are newer than the library.  Returns the library path."""
+    """Compile what is newer than its object file (one hipcc process per stale source, run side by side),
+    then link.  Returns the library path."""
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libtgcn.so cannot be built (ROCm toolchain required)")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
+             "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+    jobs, objs = [], []
     for s in SOURCES:
-        cmd += ["-x", "hip", os.path.join(CSRC, s)]
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + HEADERS):
+            tmp = obj + ".tmp%d" % os.getpid()
+            cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", tmp]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((s, obj, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for s, obj, tmp, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            failed.append(f"{s}:\n{out}")
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        else:
+            os.replace(tmp, obj)
+    if failed:
+        raise RuntimeError("hipcc failed building libtgcn.so:\n" + "\n".join(failed))
     tmp = LIB_PATH + ".tmp%d" % os.getpid()
-    cmd += ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed building libtgcn.so:\n" + res.stdout)
+        raise RuntimeError("hipcc failed linking libtgcn.so:\n" + res.stdout)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

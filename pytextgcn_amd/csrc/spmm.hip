@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
                     if (u0 + u >= G) v[u] = 0.f;
                     const float *xsrc = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
                     x[u] = *reinterpret_cast<const float4 *>(xsrc);
+                    // padding entries (weight 0) re-read the last real column: their operand must not
+                    // reach the sum, or 0 * inf = nan would appear where the reference has inf
+                    if (u0 + u >= nb) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
 #pragma unroll
                     for (int k = 0; k < KPL; ++k)
                         if (sl + k * LPR == t[u]) loss += lse - x[u][k];
+                    // a class index outside [0, C) poisons the loss instead of being dropped silently
+                    // (torch raises; the Python wrapper checks the labels once per tensor)
+                    if (sl == 0 && (t[u] < 0 || t[u] >= C)) loss = NAN;
                 }
                 if (dlogits != nullptr && valid[u]) {
                     float *drow = dlogits + r[u] * ldd;
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                 int64_t t = 0;
                 if (on) {
                     t = target[r];
-                    if (sl == 0) loss += lse - row[t];
+                    // no read outside the row: an invalid class index poisons the loss (see above)
+                    if (sl == 0) loss += (t >= 0 && t < C) ? lse - row[t] : NAN;
                 }
                 if (dlogits != nullptr && valid) {
                     float *drow = dlogits + r * ldd;

@@ -37,6 +37,31 @@ def _mask_count(mask: Tensor) -> int:
     return count
 
 
+_TARGET_OK: dict = {}
+
+
+def _check_targets(target: Tensor, mask: Tensor, C: int) -> None:
+    """Class indices of the selected rows must lie in [0, C): torch raises for anything else (its
+    `ignore_index` is not implemented here), and the kernel would otherwise index outside the row.
+    Labels and masks are static across epochs (text2graph.py:180-191), so the check -- one device sync
+    -- runs once per (target, mask) object pair and version."""
+    import weakref
+    key = (id(target), id(mask), C)
+    hit = _TARGET_OK.get(key)
+    if hit is not None and hit[0]() is target and hit[1]() is mask and hit[2] == (target._version, mask._version):
+        return
+    bad = ((target < 0) | (target >= C)) & mask
+    if bool(bad.any().item()):
+        t = int(target[bad][0].item())
+        raise IndexError(f"Target {t} is out of bounds for {C} classes (on a row selected by the mask)")
+    try:
+        _TARGET_OK[key] = (weakref.ref(target, lambda _, k=key: _TARGET_OK.pop(k, None)),
+                           weakref.ref(mask, lambda _, k=key: _TARGET_OK.pop(k, None)),
+                           (target._version, mask._version))
+    except TypeError:
+        pass
+
+
 def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count=None, want_pred: bool = False):
     lib = _lib.load()
     _require_cuda(logits, "logits")
@@ -49,6 +74,10 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count
         raise TypeError("mask must be a bool tensor")
     if logits.stride(1) != 1:
         logits = logits.contiguous()
+    if torch.cuda.is_current_stream_capturing():
+        pass                                   # no sync inside a HIP-graph capture: checked on the eager warm-up step
+    else:
+        _check_targets(target, mask, C)
     target = target.long().contiguous()
     mask = mask.contiguous()
     if count is None:
@@ -81,7 +110,13 @@ class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor, *_):
         (dlogits,) = ctx.saved_tensors
-        return dlogits.mul_(grad_out), None, None, None, None    # dlogits is ours: scale in place
+        # dlogits is ours: scale it in place (no second N x C pass) -- which makes this node single-use:
+        # a second backward through it (retain_graph=True) would compound the scale, so it is refused
+        if getattr(ctx, "_tgcn_used", False):
+            raise RuntimeError("masked_cross_entropy: backward was already run through this loss (its gradient "
+                               "buffer is scaled in place); recompute the loss instead of retain_graph=True")
+        ctx._tgcn_used = True
+        return dlogits.mul_(grad_out), None, None, None, None
 
 
 def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor, count=None, return_pred: bool = False):

@@ -165,6 +165,7 @@ class ShardedGraph:
         if self.exchange not in ("collective", "p2p"):
             raise ValueError("TGCN_EXCHANGE must be 'collective' or 'p2p'")
         self._xbuf = {}
+        self._stage = {}
 
     @classmethod
     def from_data(cls, g, group=None, **kw) -> "ShardedGraph":
@@ -215,6 +216,26 @@ class ShardedGraph:
         return full
 
     # ---- the distributed SpMM --------------------------------------------------------------------
+    def _stream_ordered(self, t: Tensor) -> bool:
+        """Does the group's backend order point-to-point transfers of `t` against the work queued on the
+        current stream?  RCCL does (its operations are enqueued on a stream that first waits for the
+        caller's).  A host-serviced backend (gloo) does not for DEVICE memory: ProcessGroupGloo's
+        send / recv hand the tensor's raw data pointer to a host thread, which reads and writes the
+        buffer whenever the socket is ready -- before the kernel that produces the shard has run, and
+        behind the back of the device's L2 for the receiving side.  (Its collectives and all-to-all do
+        stage CUDA tensors through pinned memory with stream events; send / recv do not.)  Host
+        tensors are always fine."""
+        return (not t.is_cuda) or dist.get_backend(self.group) == "nccl"
+
+    def _host_stage(self, name: str, shape, dtype) -> Tensor:
+        """Pinned host buffer for the staged exchange, one per (role, shape)."""
+        key = (name, tuple(shape), dtype)
+        buf = self._stage.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._stage[key] = buf
+        return buf
+
     def spmm(self, x_local: Tensor, bias: Optional[Tensor] = None, transpose: bool = False) -> Tensor:
         A, B = self.ops[1 if (transpose and not self.symmetric) else 0]
         W, hp, rp = self.world, self.hp, self.rp
@@ -222,26 +243,33 @@ class ShardedGraph:
             raise ValueError(f"operand has {x_local.shape[0]} rows, this rank owns {self.n_local}")
         x_local = x_local.contiguous()
         F = x_local.size(1)
-        key = (F, x_local.dtype)
+        key = (F, x_local.dtype, x_local.device)
         xbuf = self._xbuf.get(key)
         if xbuf is None:                       # gathered hub block only: the own rows are read in place
             xbuf = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
-            self._xbuf = {key: xbuf}
+            self._xbuf[key] = xbuf             # one per width: layer-1 / layer-2 widths alternate
         if hp == 0:
             raise ValueError("a sharded graph needs at least one hub node per rank")
         p2p = self.exchange == "p2p"
-        ag = self._all_gather_p2p(xbuf, x_local[:hp]) if p2p else \
-            [dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)]
+        direct = self._stream_ordered(x_local)
+        if not p2p:
+            ag = [dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)]
+        elif direct:
+            ag = self._all_gather_p2p(xbuf, x_local[:hp])
+        else:
+            ag = self._all_gather_p2p_staged(xbuf, x_local[:hp])
         rs = rs_out = None
         if A is not None:
             partial = A.spmm(x_local[hp:])                       # overlaps the all-gather
             for w in ag:
                 w.wait()
-            if p2p:
+            if p2p and direct:
                 # reduce-scatter as an all-to-all of the W slices (every pair of GPUs talks over its own
                 # xGMI link at the same time) + a local sum in rank order
                 rs_out = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
                 rs = dist.all_to_all_single(rs_out, partial, group=self.group, async_op=True)
+            elif p2p:
+                rs_out, rs = self._all_to_all_staged(partial)
             else:
                 rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
                 rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
@@ -256,7 +284,8 @@ class ShardedGraph:
         return y
 
     def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):
-        """All-gather as W - 1 direct sends and receives per rank, batched into one group call."""
+        """All-gather as W - 1 direct sends and receives per rank, batched into one group call.  Only for
+        transfers the backend orders on the stream (`_stream_ordered`)."""
         hp = self.hp
         ranks = dist.get_process_group_ranks(self.group)
         ops = []
@@ -266,6 +295,44 @@ class ShardedGraph:
                 ops.append(dist.P2POp(dist.irecv, xbuf[q * hp:(q + 1) * hp], ranks[q], group=self.group))
         xbuf[self.rank * hp:(self.rank + 1) * hp].copy_(shard)
         return dist.batch_isend_irecv(ops) if ops else []
+
+    def _all_gather_p2p_staged(self, xbuf: Tensor, shard: Tensor):
+        """The same exchange for device tensors over a host-serviced backend: the shard goes to pinned
+        host memory with a BLOCKING copy (ordered after the kernel that produced it), the transfers run
+        host to host, and the gathered block returns with a blocking host-to-device copy (ordered before
+        the SpMM that reads it, and visible to it: the copy engine, not a host store through the PCIe
+        BAR, writes the rows).  No overlap with the local SpMM -- this form only serves rehearsals of
+        the N > 1 code path on boxes without RCCL peers."""
+        hp, W = self.hp, self.world
+        ranks = dist.get_process_group_ranks(self.group)
+        send = self._host_stage("ag_send", shard.shape, shard.dtype)
+        recv = self._host_stage("ag_recv", xbuf.shape, xbuf.dtype)
+        send.copy_(shard)                                           # device -> host, synchronous
+        recv[self.rank * hp:(self.rank + 1) * hp].copy_(send)
+        ops = []
+        for q in range(W):
+            if q != self.rank:
+                ops.append(dist.P2POp(dist.isend, send, ranks[q], group=self.group))
+                ops.append(dist.P2POp(dist.irecv, recv[q * hp:(q + 1) * hp], ranks[q], group=self.group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        xbuf.copy_(recv)                                            # host -> device, synchronous
+        return []
+
+    def _all_to_all_staged(self, partial: Tensor):
+        """all_to_all_single of the hub partial sums through pinned host memory (see above)."""
+        src = self._host_stage("a2a_src", partial.shape, partial.dtype)
+        dst = self._host_stage("a2a_dst", partial.shape, partial.dtype)
+        src.copy_(partial)                                          # synchronous: `partial` is complete
+        dist.all_to_all_single(dst, src, group=self.group)
+        out = torch.empty_like(partial)
+        out.copy_(dst)
+
+        class _Done:
+            @staticmethod
+            def wait():
+                return True
+        return out, _Done
 
     def colsum_real(self, g_local: Tensor) -> Tensor:
         """Column sums over this rank's real rows (padding rows carry zero gradient by

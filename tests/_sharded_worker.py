@@ -218,8 +218,12 @@ def main(rank, world, port, kinds, errfile, backend="gloo", device="cpu"):
     torch.set_num_threads(2)
     try:
         if device != "cpu":
+            device = device.format(rank=rank)              # "cuda:{rank}": one GPU per rank
             torch.cuda.set_device(torch.device(device))
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         for kind in kinds:
             check(kind, device)
         dist.barrier()

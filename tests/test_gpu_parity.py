@@ -336,21 +336,56 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
     del rows, rowsum
 
 
-def test_config_c4_row_block_against_reference_formulation(cuda):
-    """Rows [0, 60 000) of the c4 operator (all word rows up to 1.3 M non-zeros each, ~10 M
-    non-zeros in total) against the C CSR oracle on the host."""
+def _oracle_csr(ei, w, N, rows=None):
+    """The ORACLE's normalisation (oracle/gcn_oracle.py: add_remaining_self_loops + gcn_norm, the PyG-1.6.3
+    algorithm the reference runs at textgcn/lib/models.py:11-20) as CSR with the entries of a row sorted by
+    column, ties in edge order -- the order the plan documents.  `rows=(lo, hi)` keeps the target rows
+    [lo, hi) only (the degrees still come from every edge)."""
+    tgt, src, nw = O.normalized_coo(ei.cpu(), None if w is None else w.cpu(), N)
+    lo, hi = (0, N) if rows is None else rows
+    if rows is not None:
+        keep = (tgt >= lo) & (tgt < hi)
+        tgt, src, nw = tgt[keep], src[keep], nw[keep]
+    order = torch.argsort(tgt * N + src, stable=True)
+    rp = torch.zeros(hi - lo + 1, dtype=torch.int64)
+    rp[1:] = torch.bincount(tgt - lo, minlength=hi - lo).cumsum(0)
+    return rp, src[order].to(torch.int32), nw[order]
+
+
+def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref):
+    """Index arrays bit-exact; weights within 2e-6 of the largest one (the 1-ulp association difference of
+    DESIGN.md section 1 plus the oracle's sequential fp32 degree sums) and, entry by entry, within 1e-3
+    relative (a hub row's degree is a sequential fp32 sum of ~10^6 terms in the oracle)."""
+    assert torch.equal(rp.cpu().long(), rp_ref)
+    assert torch.equal(col.cpu(), col_ref)
+    v, vr = val.cpu().double(), val_ref.double()
+    assert (v - vr).abs().max().item() <= 2e-6 * vr.abs().max().item()
+    assert bool(((v - vr).abs() <= 1e-3 * vr.abs() + 1e-30).all())
+
+
+def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
+    """The c4 plan (50 M edges) against the oracle's OWN normalisation, not against itself: rowptr / col
+    bit-exact, values to 2e-6; then rows [0, 60 000) of M @ X (all word rows up to 1.3 M non-zeros each,
+    ~10 M non-zeros) against the C CSR oracle run on the ORACLE's CSR."""
     N, E, F = 2_000_000, 50_000_000, 200
     g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    assert plan.stats()["hot_rows"] > 0                         # the benchmark configuration of the kernels
+    rp_ref, col_ref, val_ref = _oracle_csr(g.edge_index, g.edge_attr, N)
+    rp, col, val = plan.export_csr()
+    _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref)
+    del rp, col, val
     R = 60_000
     gen = torch.Generator(device=cuda).manual_seed(2)
     x = torch.randn(N, F, device=cuda, generator=gen)
-    out = plan.spmm(x)[:R].cpu()
-    rp, col, val = plan.export_csr()
-    nn_ = rp[R].item()
-    ref = csr_oracle.csr_spmm(rp[:R + 1].cpu().long(), col[:nn_].cpu(), val[:nn_].cpu(), x.cpu(),
-                              acc64=True)
+    b = torch.randn(F, device=cuda, generator=gen)
+    out = plan.spmm(x, b)[:R].cpu()
+    nn_ = rp_ref[R].item()
+    ref = csr_oracle.csr_spmm(rp_ref[:R + 1], col_ref[:nn_], val_ref[:nn_], x.cpu(), b.cpu(), acc64=True)
     assert rel_err(out, ref) < TOL
+    # the transposed path reuses the same block (M is bitwise symmetric): same rows, same oracle
+    out_t = plan.spmm(x, None, transpose=True)[:R].cpu()
+    assert rel_err(out_t, ref - b.cpu()) < TOL
 
 
 # ------------------------------------------------------------------------------------------------
@@ -554,12 +589,12 @@ def test_config_c3_dbpedia_shaped_graph(cuda):
 
 def test_config_c5_power_law_graph_h256(cuda):
     """8 M nodes / 200 M edges, degree ~ power law, h = 256 (BASELINE.json configs[4]); no hub/regular
-    structure, asserted through size-independent properties and sampled rows."""
+    structure.  A row block and the heaviest rows are checked against the ORACLE's normalisation and the C
+    CSR oracle; the whole result through size-independent properties and sampled rows."""
     N, E, F = 8_000_000, 200_000_000, 256
     g = synth.power_law_graph(N, E, seed=44, device=cuda)
     assert g.edge_index.shape == (2, E)
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
-    del g
     assert plan.symmetric and plan.nnz == E + N
     gen = torch.Generator(device=cuda).manual_seed(5)
     x = torch.randn(N, F, device=cuda, generator=gen)
@@ -568,6 +603,35 @@ def test_config_c5_power_law_graph_h256(cuda):
     deg = (rp[1:] - rp[:-1]).long()
     assert deg.max().item() > 10_000                          # heavy tail: long rows are split
     assert plan.stats()["long_rows"] > 0
+    # oracle normalisation of the target rows [0, R) and of the six heaviest rows
+    R = 150_000
+    ei_cpu, w_cpu = g.edge_index.cpu(), g.edge_attr.cpu()
+    del g
+    tgt, src, nw = O.normalized_coo(ei_cpu, w_cpu, N)
+    del ei_cpu, w_cpu
+    heavy = deg.topk(6).indices.cpu()
+    pick = (tgt < R) | torch.isin(tgt, heavy)
+    tgt, src, nw = tgt[pick], src[pick], nw[pick]
+    order = torch.argsort(tgt * N + src, stable=True)
+    tgt, src, nw = tgt[order], src[order].to(torch.int32), nw[order]
+    nb = int((tgt < R).sum())
+    rp_ref = torch.zeros(R + 1, dtype=torch.int64)
+    rp_ref[1:] = torch.bincount(tgt[:nb], minlength=R).cumsum(0)
+    e_r = rp[R].item()
+    _assert_csr_equal(rp[:R + 1], col[:e_r], val[:e_r], rp_ref, src[:nb], nw[:nb])
+    ref = csr_oracle.csr_spmm(rp_ref, src[:nb], nw[:nb], x.cpu(), acc64=True)
+    assert rel_err(y[:R], ref) < TOL
+    xc = x.cpu()
+    for r in heavy.tolist():
+        if r < R:
+            continue
+        sel = tgt == r
+        s, e = rp[r].item(), rp[r + 1].item()
+        assert torch.equal(col[s:e].cpu(), src[sel])
+        assert (val[s:e].cpu().double() - nw[sel].double()).abs().max().item() <= 2e-6 * nw[sel].abs().max().item()
+        want = (nw[sel].double().unsqueeze(1) * xc[src[sel].long()].double()).sum(0)
+        assert rel_err(y[r], want.float()) < TOL, r
+    del tgt, src, nw, xc, ref
     rows = torch.cat([deg.topk(6).indices, torch.randint(0, N, (150,), device=cuda, generator=gen)]).tolist()
     for r in rows:
         s, e = rp[r].item(), rp[r + 1].item()
@@ -939,6 +1003,48 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
             plan.spmm(xd, bd, out=out[:, 4:4 + F])
             assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and bool((out[:, :4] == 7).all())
     plan.close(); plain.close()
+
+
+@pytest.mark.parametrize("F", [200, 64, 32, 7])          # wide, sub-group (16 / 8 lanes per row) and scalar kernels
+def test_non_finite_operand_rows_with_and_without_the_hot_block(cuda, monkeypatch, F):
+    """An `inf` in ONE operand row.  Reference semantics (gather -> scale -> scatter_add, models.py:20): it
+    reaches exactly the result rows that have an edge from that column.  The gather kernels reproduce that,
+    so a plan built with TGCN_HOT_ROWS=0 matches the oracle row for row, non-finite entries included.  The
+    dense hot block (default on word-document shapes) multiplies EVERY operand row by a possibly-zero
+    weight, so there 0 * inf = nan also lands in hot rows WITHOUT an edge to the column: the documented
+    deviation (include/tgcn.h), confined to the hot rows and to the poisoned feature column."""
+    n, n_hubs = 6000, 12
+    gen = torch.Generator().manual_seed(77)
+    ei, w = _hub_graph(n, n_hubs, gen)
+    bad_col, bad_feat = 4321, 5
+    x = torch.randn(n, F, generator=gen)
+    x[bad_col, bad_feat] = float("inf")
+    ref = oracle_spmm(ei, w, n, x)
+    touched = ~torch.isfinite(ref[:, bad_feat])
+    assert 0 < int(touched.sum()) < n                           # some rows see the column, most do not
+    hubs_without_edge = [h for h in range(n_hubs) if not bool(touched[h])]
+    assert hubs_without_edge                                    # the case the two semantics differ on
+
+    monkeypatch.setenv("TGCN_HOT_ROWS", "0")
+    plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    monkeypatch.delenv("TGCN_HOT_ROWS")
+    assert plain.stats()["hot_rows"] == 0
+    got = plain.spmm(x.to(cuda)).cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))
+    assert torch.equal(got[~torch.isfinite(ref)], ref[~torch.isfinite(ref)])      # +inf where the oracle has +inf
+    fin = torch.isfinite(ref)
+    assert (got[fin] - ref[fin]).abs().max().item() < TOL * ref[fin].abs().max().item()
+
+    hot = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    assert hot.stats()["hot_rows"] == n_hubs
+    got_h = hot.spmm(x.to(cuda)).cpu()
+    differs = torch.isfinite(got_h) != torch.isfinite(ref)
+    rows, feats = differs.nonzero(as_tuple=True)
+    assert set(feats.tolist()) <= {bad_feat}                    # only the poisoned feature column ...
+    # ... and only hot rows without that edge (the scalar kernel, F % 4 != 0, never uses the hot block)
+    assert set(rows.tolist()) == (set(hubs_without_edge) if F % 4 == 0 else set())
+    same = ~differs & fin
+    assert (got_h[same] - ref[same]).abs().max().item() < TOL * ref[fin].abs().max().item()
 
 
 def test_dense_hot_block_is_chosen_for_the_benchmark_shapes_only_when_it_pays(cuda):
