@@ -51,7 +51,9 @@ struct DevBuf {
 
 constexpr int kThreads = 256;
 
-inline int grid_for(int64_t n, int per_block = kThreads, int cap = 1 << 20) {
+// `cap` is for grid-stride kernels only; kernels that map one thread (or wave) to one element take the
+// default, the launch limit itself (2^31 - 1 workgroups in x), so that no element is ever left out
+inline int grid_for(int64_t n, int per_block = kThreads, int cap = INT32_MAX) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
@@ -126,25 +128,27 @@ __global__ void k_rowptr(const uint64_t *__restrict__ keys, int64_t nnz, int64_t
 __global__ void k_deg_inv_sqrt(const int32_t *__restrict__ rowptr, const float *__restrict__ vals,
                                int64_t N, float *__restrict__ dis) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= N) return;
-    const int32_t b = rowptr[r], e = rowptr[r + 1];
-    // eight independent partial sums per lane: the hottest word row of c4 has ~10^6 entries and a
-    // single dependent chain per lane made this kernel latency-bound (7.3 ms -> see profiles/)
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int32_t j = b + lane;
-    for (; j + 7 * 64 < e; j += 8 * 64) {
+    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
+    // grid-stride over the rows: the launch grid is capped (grid_for), N is not -- config c5 has 8 M rows
+    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        // eight independent partial sums per lane: the hottest word row of c4 has ~10^6 entries and a
+        // single dependent chain per lane made this kernel latency-bound (7.3 ms -> see profiles/)
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int32_t j = b + lane;
+        for (; j + 7 * 64 < e; j += 8 * 64) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += vals[j + u * 64];
-    }
-    for (; j < e; j += 64) acc[0] += vals[j];
-    float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            for (int u = 0; u < 8; ++u) acc[u] += vals[j + u * 64];
+        }
+        for (; j < e; j += 64) acc[0] += vals[j];
+        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) {
-        float d = 1.0f / sqrtf(s);  // deg.pow(-0.5)
-        if (isinf(d)) d = 0.0f;     // masked_fill_(== inf, 0)
-        dis[r] = d;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            float d = 1.0f / sqrtf(s);  // deg.pow(-0.5)
+            if (isinf(d)) d = 0.0f;     // masked_fill_(== inf, 0)
+            dis[r] = d;
+        }
     }
 }
 
@@ -691,7 +695,7 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
                                                        rowptr.as<int32_t>());
     TGCN_HIP_CHECK(hipGetLastError());
     if (normalize && N > 0) {
-        k_deg_inv_sqrt<<<grid_for(N, kThreads / 64), kThreads, 0, stream>>>(
+        k_deg_inv_sqrt<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(
             rowptr.as<int32_t>(), vals_b.as<float>(), N, dis.as<float>());
         TGCN_HIP_CHECK(hipGetLastError());
     }
