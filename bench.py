@@ -44,15 +44,32 @@ def parse():
     p.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
-    p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
+    p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 32)
+    p.add_argument("--no-hbm-activity", action="store_true", help="skip the live memory-controller measurement")
     return p.parse_args()
 
 
-def cpu_baseline(plan, F, frac, seed=44):
-    """Reference formulation (PyG-1.6.3 index_select -> scale -> scatter_add, oracle/gcn_oracle.py
-    `propagate`) on the host cores, over the sub-operator whose TARGET rows are a random `frac`
-    of the nodes (forward) and its transpose (backward).  Bounded sample of the same workload."""
-    from oracle import gcn_oracle as O
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5):
+    """The two CPU rows of BASELINE.md section 3, on this box's host cores, same graph / seed / fp32,
+    `warm` warm-up + `reps` timed repetitions each, median:
+      CPU-ref (`value`)  the reference formulation (PyG-1.6.3 index_select -> scale -> scatter_add,
+                         oracle/gcn_oracle.py `propagate`) over the sub-operator whose TARGET rows are a random
+                         `frac` of the nodes (forward) and its transpose (backward): a bounded sample, because
+                         the formulation materialises two nnz x F temporaries (41.6 GB each at full c4);
+      CPU-csr (`csr`)    the C / OpenMP CSR restatement (oracle/csr_spmm.c, `oracle_csr_spmm_f32`) of M @ X and
+                         M^T @ G on the FULL operator."""
+    from oracle import csr_oracle, gcn_oracle as O
     N = plan.num_nodes
     gen = torch.Generator().manual_seed(seed)
     rp, col, val = (t.cpu() for t in plan.export_csr())
@@ -61,26 +78,54 @@ def cpu_baseline(plan, F, frac, seed=44):
     rows = torch.repeat_interleave(torch.arange(N), deg)
     sel = pick[rows]
     tgt, src, w = rows[sel], col[sel].long(), val[sel]
+    del rows, sel
     n_edges = int((tgt != src).sum())                       # self-loops are not graph edges
     x = torch.randn(N, F, generator=gen)
     fwd = torch.stack([src, tgt])                           # out[tgt] += w * x[src]
     bwd = torch.stack([tgt, src])                           # dxw[src] += w * g[tgt]
     times = []
-    for rep in range(3):
+    for rep in range(warm + reps):
         t0 = time.perf_counter()
         O.propagate(fwd, x, w, N)
-        t1 = time.perf_counter()
         O.propagate(bwd, x, w, N)
-        t2 = time.perf_counter()
-        if rep:                                             # first repetition is the warm-up
-            times.append((t1 - t0) + (t2 - t1))
-    t = sorted(times)[len(times) // 2]
-    return {"value": 2.0 * n_edges / t, "unit": "edges/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"reference formulation (gather->scale->index_add, fwd+bwd) on the rows of a "
-                      f"random {frac:.4f} of the nodes of the same graph: {n_edges} edges, "
-                      f"{int(sel.sum())} non-zeros, F={F}, median of 2 timed reps, "
-                      f"{t:.2f} s per fwd+bwd pair, os.cpu_count()={os.cpu_count()}"}
+        if rep >= warm:
+            times.append(time.perf_counter() - t0)
+    t_ref = sorted(times)[len(times) // 2]
+    n_sel = int(w.numel())
+    del fwd, bwd, tgt, src, w
+    # CPU-csr at full size (the operator is symmetric here; otherwise the transposed CSR is exported)
+    rp64 = rp.long()
+    if plan.symmetric:
+        rpt, colt, valt = rp64, col, val
+    else:
+        rpt, colt, valt = (t.cpu() for t in plan.export_csr(transpose=True))
+        rpt = rpt.long()
+    lib = csr_oracle.lib()
+    y = torch.empty(N, F)
+
+    def csr(rp_, col_, val_):
+        lib.oracle_csr_spmm_f32(N, rp_.data_ptr(), col_.data_ptr(), val_.data_ptr(), x.data_ptr(), x.stride(0), F,
+                                None, y.data_ptr(), y.stride(0))
+    times = []
+    for rep in range(warm + reps):
+        t0 = time.perf_counter()
+        csr(rp64, col, val)
+        csr(rpt, colt, valt)
+        if rep >= warm:
+            times.append(time.perf_counter() - t0)
+    t_csr = sorted(times)[len(times) // 2]
+    threads = torch.get_num_threads()
+    return {"value": 2.0 * n_edges / t_ref, "unit": "edges/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+            "sample": f"CPU-ref: reference formulation (gather->scale->index_add, fwd+bwd) on the rows of a "
+                      f"random {frac:.4f} of the nodes of the same graph: {n_edges} edges, {n_sel} non-zeros, "
+                      f"F={F}, {warm} warm-up + {reps} timed reps, median {t_ref:.2f} s per fwd+bwd pair, "
+                      f"torch threads {threads}",
+            "csr": {"value": 2.0 * E / t_csr, "unit": "edges/s", "kind": "port",
+                    "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                    "sample": f"CPU-csr: oracle_csr_spmm_f32 (C, OpenMP) M@X and M^T@G on the FULL operator, "
+                              f"{int(plan.nnz)} non-zeros, F={F}, {warm} warm-up + {reps} timed reps, median "
+                              f"{t_csr:.3f} s per fwd+bwd pair"}}
 
 
 def device_copy_gbps(dev, n_bytes=1 << 30, reps=10):
@@ -100,16 +145,66 @@ def device_copy_gbps(dev, n_bytes=1 << 30, reps=10):
     return 2.0 * n_bytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
 
 
-def measured_traffic(config, n_gpus):
-    """HBM bytes per SpMM launch from rocprofv3 PMC passes (profiles/traffic.json, collected and
-    corrected as MI355X_MICROARCH.md 'HBM' prescribes); None when no measurement is on file."""
+def fabric_traffic(config, n_gpus):
+    """L2 <-> fabric bytes per SpMM launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    2*FETCH_SIZE + WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md 'HBM' prescribes).  Returns
+    (bytes, provenance) or (None, None).  NOT measured by this run: a constant from the named profile."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            rec = json.load(f)
-        return rec.get(f"{config}_n{n_gpus}", {}).get("bytes_per_launch")
+            rec = json.load(f).get(f"{config}_n{n_gpus}", {})
+        if "bytes_per_launch" in rec:
+            return rec["bytes_per_launch"], f"profiles/traffic.json[{config}_n{n_gpus}] ({rec.get('round', '?')})"
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
+def profile_constant(key):
+    """A number recorded under profiles/ (e.g. the L2-resident ceiling of tools/ceiling_spmm.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "constants.json")) as f:
+            return json.load(f).get(key)
     except (OSError, ValueError):
         return None
+
+
+def hbm_activity(step_fn, dev, seconds=1.5):
+    """What this run's SpMM actually pulls from HBM, measured live: the memory controllers' busy percentage
+    (sysfs `mem_busy_percent`, sampled at 100 Hz while `step_fn` loops) calibrated against a 1 GiB device copy
+    whose HBM bytes are known (tools/hbm_activity.py; round-2 profile profiles/r02_hbm_activity.md shows the
+    percentage is linear in bytes/s for copy / read-only / write-only streams).  Outside the timed region.
+    Returns None when the box does not expose the counter."""
+    try:
+        from tools import hbm_activity as H
+        sysdir = H.find_sysfs(dev.index or 0)
+        if sysdir is None:
+            return None
+        n = 1 << 28
+        a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        quiet = open(os.devnull, "w")
+        old = sys.stdout
+        sys.stdout = quiet                        # H.measure prints its records
+        try:
+            idle = H.measure("idle", lambda: None, sysdir, 0.5)
+            cal = H.measure("copy", lambda: b.copy_(a), sysdir, seconds, bytes_known=2 * n * 4)
+            del a, b
+            run = H.measure("step", step_fn, sysdir, seconds)
+        finally:
+            sys.stdout = old
+            quiet.close()
+        base = idle["mem_busy_percent_median"] or 0.0
+        if not cal["mem_busy_percent_median"] or run["mem_busy_percent_median"] is None:
+            return None
+        gbps_per_pct = cal["known_hbm_GBps"] / max(cal["mem_busy_percent_median"] - base, 1e-9)
+        gbps = (run["mem_busy_percent_median"] - base) * gbps_per_pct
+        return {"hbm_GBps": gbps, "ms_per_step": run["ms_per_launch"],
+                "bytes_per_step": gbps * 1e9 * run["ms_per_launch"] * 1e-3,
+                "mem_busy_percent": run["mem_busy_percent_median"],
+                "calibration": {"copy_GBps": cal["known_hbm_GBps"], "copy_mem_busy_percent": cal["mem_busy_percent_median"]}}
+    except Exception as e:                        # noqa: BLE001 - a diagnostic must never sink the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
 def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False):
@@ -423,6 +518,10 @@ def main():
     launch_bytes = 0.5 * (bytes_fwd + bytes_bwd)
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
 
+    # what the SpMM pulls from HBM, measured live on this box (outside the timed region; N = 1 only: at N > 1
+    # the step contains collectives every rank must enter)
+    hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
+
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
@@ -439,6 +538,46 @@ def main():
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        # ---- roofline of the dominant kernel family (one tgcn_spmm launch), four ways of counting bytes ----
+        #   algorithmic  SURVEY 8(d): every gathered row charged to HBM (no cache reuse assumed).  > peak on
+        #                this path: the word block is served by L2 / Infinity Cache and the dense hot block
+        #                reads X once -- it measures work done, not memory traffic;
+        #   hbm          bytes the memory controllers actually moved (live, `hbm_activity`)  -> `frac`;
+        #   fabric       L2 <-> fabric bytes from the committed rocprofv3 PMC passes (Infinity-Cache hits
+        #                included: an upper bound on HBM bytes; the link the kernel is in fact bound by);
+        #   compulsory   every input and output touched exactly once (lower bound).
+        per_s = 1.0 / (launch_ms * 1e-3) / 1e9
+        n_out = N if parallelism == "single" else sg.n_local
+        compulsory = 8 * plan.nnz + 4 * n_out + 8 * n_out * F if parallelism == "single" else None
+        fabric, fabric_src = fabric_traffic(args.config, world)
+        hbm_bytes = None
+        if hbm and "bytes_per_step" in hbm:
+            hbm_bytes = hbm["bytes_per_step"] / 2.0            # a step is two launches (forward, transposed)
+        if hbm_bytes is not None:
+            frac, frac_basis = hbm_bytes * per_s / HBM_PEAK_GBPS, "hbm bytes measured live (memory-controller activity)"
+        elif fabric is not None:
+            frac, frac_basis = fabric * per_s / HBM_PEAK_GBPS, "fabric counter bytes from " + fabric_src + " (upper bound on HBM)"
+        else:
+            frac, frac_basis = min(achieved / HBM_PEAK_GBPS, 1.0), "algorithmic bytes, capped (no traffic measurement on file)"
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": frac, "frac_basis": frac_basis,
+            "traffic": hbm_bytes if hbm_bytes is not None else fabric,
+            "traffic_basis": ("live: sysfs mem_busy_percent while the step loops, calibrated on a 1 GiB device copy"
+                              if hbm_bytes is not None else fabric_src),
+            "hbm_activity": hbm,
+            "frac_algorithmic": achieved / HBM_PEAK_GBPS,
+            "traffic_fabric": fabric, "traffic_fabric_source": fabric_src,
+            "frac_traffic": None if fabric is None else fabric * per_s / HBM_PEAK_GBPS,
+            "compulsory_bytes_per_launch": compulsory,
+            "frac_compulsory": None if compulsory is None else compulsory * per_s / HBM_PEAK_GBPS,
+            "l2_resident_ceiling_ms": profile_constant(f"{args.config}_F{F}_l2_resident_ceiling_ms"),
+            "kernel": "one tgcn_spmm launch: k_spmm_gather (+ k_spmm_hot, k_spmm_sweep, k_spmm_fix)" if parallelism == "single"
+                      else "one distributed SpMM on this rank: local SpMM launches + RCCL all-gather / reduce-scatter",
+            # secondary denominator: this box's device-to-device copy rate (read + write)
+            "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
+            "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
+            "algorithmic_bytes_per_launch": launch_bytes}
         out = {
             "metric": "edges/sec (fwd+bwd SpMM), 2M-node/50M-edge graph h=200"
                       if args.config == "c4" else f"edges/sec (fwd+bwd SpMM), {args.config}",
@@ -454,15 +593,7 @@ def main():
             "config": {"workload": f"{args.config}: synthetic PMI/TF-IDF word-doc graph, N={N}, E={E}, "
                                    f"nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G",
                        "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(args.config, world),
-                         "kernel": "one tgcn_spmm launch: k_spmm_gather (+ k_spmm_hot, k_spmm_fix)" if parallelism == "single"
-                                   else "one distributed SpMM on this rank: local k_spmm_gather launches + RCCL all-gather / reduce-scatter",
-                         # secondary denominator: this box's device-to-device copy rate (read + write)
-                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
-                         "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
-                         "algorithmic_bytes_per_launch": launch_bytes},
+            "roofline": roofline,
             "epoch_ms": epoch_ms,
             "epoch_ms_fused": epoch_ms_fused,
             # NOT part of the metric: the fused loop with pytextgcn_amd.enable_activation_reuse(), which
@@ -475,7 +606,7 @@ def main():
             "exchange_diagnostics": diagnostics,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
-            out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac)
+            out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_sharded:
         more = exchange_diagnostics(sg, F, dev, dist, extra=True)

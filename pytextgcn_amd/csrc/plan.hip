@@ -279,6 +279,45 @@ __global__ void k_hot_fill(const int32_t *__restrict__ hot_rows, const int32_t *
     }
 }
 
+// Column-sweep block: sort keys of the entries of the swept rows.  Row m of the list (blockIdx.y) is CSR
+// row srow[m], local row sli[m] = slot * rw + row_in_slot; entry j of it goes to position soff[m] + (j -
+// rowptr[row]).  Key = (label * 512 + slot) << 32 | (block >> 3) << 14 | row_in_slot << 11 | column % 2048
+// with block = column / 2048 and label = block % 8: after a stable sort every (label, slot) owns one
+// contiguous run ordered by column block, then row, then column (ties: storage order).
+constexpr int kSweepBlockBits = 11;    // 2048 operand rows per column block (1.6 MB at F = 200)
+
+__global__ void k_sweep_keys(const int32_t *__restrict__ srow, const int32_t *__restrict__ sli,
+                             const int64_t *__restrict__ soff, int rw, const int32_t *__restrict__ rowptr,
+                             const int2 *__restrict__ cv, uint64_t *__restrict__ keys, float *__restrict__ vals) {
+    const int m = blockIdx.y;
+    const int32_t r = srow[m], li = sli[m];
+    const uint32_t slot = static_cast<uint32_t>(li / rw), ris = static_cast<uint32_t>(li % rw);
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    const int64_t o = soff[m];
+    for (int32_t j = b + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
+        const int2 p = cv[j];
+        const uint32_t c = static_cast<uint32_t>(p.x), blk = c >> kSweepBlockBits;
+        const uint64_t hi = (blk & 7u) * kSweepSlots + slot;
+        const uint32_t lo = ((blk >> 3) << 14) | (ris << kSweepBlockBits) | (c & ((1u << kSweepBlockBits) - 1u));
+        keys[o + (j - b)] = (hi << 32) | lo;
+        vals[o + (j - b)] = __int_as_float(p.y);
+    }
+}
+
+__global__ void k_sweep_unpack(const uint64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n,
+                               int2 *__restrict__ scv) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint64_t k = keys[j];
+        const uint32_t hi = static_cast<uint32_t>(k >> 32), lo = static_cast<uint32_t>(k);
+        const uint32_t label = hi / kSweepSlots;
+        const uint32_t blk = ((lo >> 14) << 3) | label;
+        const uint32_t col = (blk << kSweepBlockBits) | (lo & ((1u << kSweepBlockBits) - 1u));
+        const uint32_t ris = (lo >> kSweepBlockBits) & 7u;
+        scv[j] = make_int2(static_cast<int>(col | (ris << kSweepRowShift)), __float_as_int(vals[j]));
+    }
+}
+
 // Tuning knobs (tools/sweep_spmm.py); the defaults are the measured best on config c4.
 struct Knobs {
     int col_block;  // columns per block for long-row cuts; 0 = no column cuts
@@ -287,6 +326,10 @@ struct Knobs {
                     // 4 = interleaved in XCD-affine queues (column block j -> XCD j % 8)
     int hot_rows;   // 0 = never build the dense hot block
     double hot_ratio;  // build it when the 32 longest rows hold >= hot_ratio * n_cols entries
+    int sweep_rows;      // most rows the column-sweep block may take (0 = never build it; <= 4096)
+    int sweep_min_rows;  // ... and fewest: below this the block is not worth a launch
+    double sweep_share;  // build it when those rows hold >= sweep_share * nnz entries
+    int sweep_min_cols;  // ... and the operand has at least this many rows (smaller ones sit in L2 anyway)
 };
 
 Knobs knobs_from_env() {
@@ -301,6 +344,11 @@ Knobs knobs_from_env() {
     k.hot_rows = geti("TGCN_HOT_ROWS", 1);
     const char *hr = std::getenv("TGCN_HOT_RATIO");
     k.hot_ratio = hr ? std::atof(hr) : 2.0;
+    k.sweep_rows = geti("TGCN_SWEEP", 1) ? std::min(geti("TGCN_SWEEP_ROWS", 4096), kSweepSlots * 8) : 0;
+    k.sweep_min_rows = std::max(1, geti("TGCN_SWEEP_MIN_ROWS", 256));
+    const char *ss = std::getenv("TGCN_SWEEP_SHARE");
+    k.sweep_share = ss ? std::atof(ss) : 0.05;
+    k.sweep_min_cols = geti("TGCN_SWEEP_MIN_COLS", 32 << kSweepBlockBits);
     return k;
 }
 
@@ -321,6 +369,8 @@ void free_block(CsrBlock &b) {
     if (b.items_all) (void)hipFree(b.items_all);
     if (b.fix_all) (void)hipFree(b.fix_all);
     if (b.hot_vals) (void)hipFree(b.hot_vals);
+    if (b.sweep_cv) (void)hipFree(b.sweep_cv);
+    if (b.sweep_ptr) (void)hipFree(b.sweep_ptr);
     b = CsrBlock{};
 }
 
@@ -460,6 +510,92 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         b.hot_vals = static_cast<float *>(d_vals.release());
     }
 
+    // The column-sweep block (spmm.hip: k_spmm_sweep).  Below the hot rows sit a few thousand word rows of
+    // 10^3..10^5 entries each.  Gathered row by row they pull every document row across the fabric once per
+    // entry (each is used ~5 times, by rows that run on different XCDs at different times: L2 cannot help).
+    // These rows are taken out of the gather partition too: 8 x 32 persistent workgroups keep their partial
+    // sums in LDS and walk the COLUMNS instead -- label x (one per XCD) takes column blocks b = x (mod 8) in
+    // ascending order, so the 2048 operand rows of a block cross the fabric once, into ONE L2, and serve every
+    // swept row from there.
+    std::vector<int32_t> sweep_of_long(static_cast<size_t>(n_long), -1);   // long-row index -> local row
+    int32_t n_sweep = 0, sweep_rw = 0, n_swept = 0;
+    if (kn.sweep_rows > 0 && n_long > 0 && b.n_cols >= kn.sweep_min_cols &&
+        b.n_cols < (int64_t(1) << kSweepRowShift)) {
+        std::vector<int32_t> cand;
+        cand.reserve(n_long);
+        for (int32_t i = 0; i < n_long; ++i)
+            if (hot_of_long[i] < 0) cand.push_back(i);
+        auto deg = [&](int32_t i) { return rp[long_rows[i] + 1] - rp[long_rows[i]]; };
+        const size_t take = std::min<size_t>(cand.size(), static_cast<size_t>(kn.sweep_rows));
+        std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [&](int32_t x, int32_t y) {
+            return deg(x) != deg(y) ? deg(x) > deg(y) : x < y;
+        });
+        int64_t total = 0;
+        for (size_t q = 0; q < take; ++q) total += deg(cand[q]);
+        size_t free_b = 0, total_b = 0;
+        const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                          static_cast<size_t>(total) * 32 + (size_t(1) << 30) < free_b;
+        (void)hipGetLastError();
+        if (static_cast<int64_t>(take) >= kn.sweep_min_rows && fits &&
+            static_cast<double>(total) >= kn.sweep_share * static_cast<double>(b.nnz)) {
+            sweep_rw = static_cast<int32_t>((take + kSweepSlots - 1) / kSweepSlots);
+            n_sweep = sweep_rw * kSweepSlots;
+            n_swept = static_cast<int32_t>(take);
+            // rows in degree order are dealt to the 512 wave slots in snake order: every slot (and so
+            // every workgroup) gets the same share of the entries
+            std::vector<int32_t> srow(take), sli(take);
+            std::vector<int64_t> soff(take);
+            int64_t off = 0;
+            int32_t max_deg = 0;
+            for (size_t q = 0; q < take; ++q) {
+                const int32_t round = static_cast<int32_t>(q / kSweepSlots), j = static_cast<int32_t>(q % kSweepSlots);
+                const int32_t slot = (round & 1) ? kSweepSlots - 1 - j : j;
+                const int32_t li = slot * sweep_rw + round;
+                sweep_of_long[cand[q]] = li;
+                srow[q] = long_rows[cand[q]];
+                sli[q] = li;
+                soff[q] = off;
+                off += deg(cand[q]);
+                max_deg = std::max(max_deg, deg(cand[q]));
+            }
+            DevBuf d_row, d_li, d_off, keys_a, keys_b, vals_a, vals_b, d_scv, d_ptr;
+            TGCN_CHECK(d_row.alloc(sizeof(int32_t) * take));
+            TGCN_CHECK(d_li.alloc(sizeof(int32_t) * take));
+            TGCN_CHECK(d_off.alloc(sizeof(int64_t) * take));
+            TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
+            TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
+            TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
+            TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
+            TGCN_CHECK(d_scv.alloc(sizeof(int2) * total));
+            TGCN_CHECK(d_ptr.alloc(sizeof(int32_t) * (kSweepLabels * kSweepSlots + 1)));
+            TGCN_HIP_CHECK(hipMemcpyAsync(d_row.p, srow.data(), sizeof(int32_t) * take, hipMemcpyHostToDevice, stream));
+            TGCN_HIP_CHECK(hipMemcpyAsync(d_li.p, sli.data(), sizeof(int32_t) * take, hipMemcpyHostToDevice, stream));
+            TGCN_HIP_CHECK(hipMemcpyAsync(d_off.p, soff.data(), sizeof(int64_t) * take, hipMemcpyHostToDevice, stream));
+            dim3 grid(static_cast<unsigned>(std::min<int64_t>((max_deg + kThreads - 1) / kThreads, 256)),
+                      static_cast<unsigned>(take));
+            k_sweep_keys<<<grid, kThreads, 0, stream>>>(d_row.as<int32_t>(), d_li.as<int32_t>(), d_off.as<int64_t>(),
+                                                        sweep_rw, b.rowptr, b.cv, keys_a.as<uint64_t>(),
+                                                        vals_a.as<float>());
+            TGCN_HIP_CHECK(hipGetLastError());
+            TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
+                                  vals_b.as<float>(), total, 32 + 12, stream));   // syncs: host vectors done
+            k_sweep_unpack<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
+                keys_b.as<uint64_t>(), vals_b.as<float>(), total, d_scv.as<int2>());
+            TGCN_HIP_CHECK(hipGetLastError());
+            k_rowptr<<<grid_for(kSweepLabels * kSweepSlots + 1), kThreads, 0, stream>>>(
+                keys_b.as<uint64_t>(), total, kSweepLabels * kSweepSlots, d_ptr.as<int32_t>());
+            TGCN_HIP_CHECK(hipGetLastError());
+            TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+            b.n_sweep = n_sweep;
+            b.sweep_rw = sweep_rw;
+            b.sweep_nnz = total;
+            b.bytes += d_scv.bytes + d_ptr.bytes;
+            b.sweep_cv = static_cast<int2 *>(d_scv.release());
+            b.sweep_ptr = static_cast<int32_t *>(d_ptr.release());
+        }
+    }
+    (void)n_swept;
+
     // pass 2: segments of the long rows, launch order, fix list.  Built once for the complete operator
     // and, when there is a hot block, once more without the hot rows (the list the float4 kernels use
     // next to k_spmm_hot; the complete list then only serves the scalar fallback kernel).
@@ -472,6 +608,7 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         std::vector<FixEntry> fix;
         int64_t slots = 0;
         int32_t hot_slot_base = 0;
+        int32_t sweep_slot_base = 0;
     };
     bool overflow = false;
     auto make_lists = [&](bool skip_hot, Lists &out) {
@@ -491,7 +628,7 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             }
         };
         for (int32_t i = 0; i < n_long; ++i) {
-            if (skip_hot && hot_of_long[i] >= 0) continue;
+            if (skip_hot && (hot_of_long[i] >= 0 || sweep_of_long[i] >= 0)) continue;
             const int32_t r = long_rows[i];
             const int64_t slot_begin = slots;
             if (n_cb > 0) {
@@ -521,6 +658,13 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             for (int32_t k = 0; k < n_hot; ++k)
                 fix.push_back({hot_rows[k], static_cast<int32_t>(slots + int64_t(k) * b.hot_parts), b.hot_parts, 0});
             slots += int64_t(n_hot) * b.hot_parts;
+            // swept row with local index li: one partial per label, carry rows [base + 8 li, base + 8 li + 8)
+            out.sweep_slot_base = static_cast<int32_t>(slots);
+            for (int32_t i = 0; i < n_long; ++i)
+                if (sweep_of_long[i] >= 0)
+                    fix.push_back({long_rows[i], static_cast<int32_t>(slots + int64_t(sweep_of_long[i]) * kSweepLabels),
+                                   kSweepLabels, 0});
+            slots += int64_t(n_sweep) * kSweepLabels;
         }
         if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) overflow = true;
         out.slots = slots;
@@ -612,12 +756,13 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
     };
 
     Lists main_lists;
-    make_lists(n_hot > 0, main_lists);
+    make_lists(n_hot > 0 || n_sweep > 0, main_lists);
     if (!overflow) {
         b.hot_slot_base = main_lists.hot_slot_base;
+        b.sweep_slot_base = main_lists.sweep_slot_base;
         TGCN_CHECK(upload(main_lists, b.items, b.n_items, b.fix, b.n_fix, b.n_segments));
     }
-    if (n_hot > 0 && !overflow) {
+    if ((n_hot > 0 || n_sweep > 0) && !overflow) {
         Lists all;
         make_lists(false, all);
         if (!overflow) TGCN_CHECK(upload(all, b.items_all, b.n_items_all, b.fix_all, b.n_fix_all, b.n_segments_all));
@@ -919,6 +1064,10 @@ int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out) {
         case TGCN_Q_N_ROWS_T: *out = t.n_rows; break;
         case TGCN_Q_HOT_ROWS: *out = f.n_hot; break;
         case TGCN_Q_HOT_ROWS_T: *out = t.n_hot; break;
+        case TGCN_Q_SWEEP_ROWS: *out = f.n_sweep; break;
+        case TGCN_Q_SWEEP_ROWS_T: *out = t.n_sweep; break;
+        case TGCN_Q_SWEEP_NNZ: *out = f.sweep_nnz; break;
+        case TGCN_Q_SWEEP_NNZ_T: *out = t.sweep_nnz; break;
         default:
             set_error("tgcn_plan_query: unknown selector %d", what);
             return TGCN_E_INVALID;

@@ -19,6 +19,7 @@
 //     write one partial per segment into the carry workspace and k_spmm_fix adds them in slot
 //     order (LDS across the 4 waves), so the result is bitwise reproducible.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,25 @@ struct Vec<4> {
     static __device__ __forceinline__ type add(const type &a, const type &b) {
         return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
+};
+typedef float native_f2 __attribute__((ext_vector_type(2)));
+template <>
+struct Vec<2> {
+    using type = float2;
+    static __device__ __forceinline__ type load_nt(const float *p) {
+        const native_f2 v = __builtin_nontemporal_load(reinterpret_cast<const native_f2 *>(p));
+        return make_float2(v.x, v.y);
+    }
+    static __device__ __forceinline__ void store_nt(float *p, const type &a) {
+        native_f2 v = {a.x, a.y};
+        __builtin_nontemporal_store(v, reinterpret_cast<native_f2 *>(p));
+    }
+    static __device__ __forceinline__ type zero() { return make_float2(0.f, 0.f); }
+    static __device__ __forceinline__ void fma(type &a, float v, const type &x) {
+        a.x = fmaf(v, x.x, a.x);
+        a.y = fmaf(v, x.y, a.y);
+    }
+    static __device__ __forceinline__ type add(const type &a, const type &b) { return make_float2(a.x + b.x, a.y + b.y); }
 };
 template <>
 struct Vec<1> {
@@ -369,6 +389,89 @@ __global__ __launch_bounds__(64 * kHotWaves) void k_spmm_hot(
     }
 }
 
+// Column sweep (plan.hip: the sweep block).  8 labels x 32 workgroups of 16 waves; wave `slot` of label x owns
+// `rw` of the swept rows and ONE contiguous run of their entries: those whose column block (2048 operand
+// rows) is = x (mod 8), ordered by column block, then row, then column.  Workgroups of one label run on one
+// XCD (workgroups are dealt round-robin over the XCDs; an observed placement that only speed depends on)
+// and walk the column blocks in the same order at the same pace -- every slot carries the same share of the
+// entries -- so a block's operand rows are fetched over the fabric once, into that XCD's L2, and gathered
+// from there by all 512 waves of the label.  The partial sums of a wave's rows live in LDS (rw x F floats
+// per wave, up to 128 KB per workgroup); the row being accumulated sits in registers and is exchanged with
+// its LDS copy when the stream moves to another row (a wave-uniform branch: the row index comes out of
+// v_readlane).  No wave ever touches another wave's rows: no barriers, no atomics, fixed summation order.
+// At the end every wave writes its rows as partial sums of label x; k_spmm_fix adds the 8 labels in order.
+template <int VEC, int U>
+__global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
+    const int2 *__restrict__ scv, const int32_t *__restrict__ sptr, int rw, const float *__restrict__ X,
+    int64_t ldx, const float *__restrict__ X2, int64_t ldx2, int split, int F, float *__restrict__ carry,
+    int64_t ldc, int slot_base) {
+    using V = Vec<VEC>;
+    using vec_t = typename V::type;
+    extern __shared__ __attribute__((aligned(16))) float sweep_acc[];   // [kSweepWaves * rw][wl]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int label = blockIdx.x & (kSweepLabels - 1);
+    const int slot = (blockIdx.x / kSweepLabels) * kSweepWaves + wave;
+    const int col0 = blockIdx.y * (64 * VEC);
+    const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;
+    const bool active = lane < nvec;
+    const int lv = (active ? lane : nvec - 1) * VEC;            // idle lanes shadow the last vector, never store
+    const int wl = ((min(F, 64 * VEC) + VEC - 1) / VEC) * VEC;  // LDS row length: the widest tile's
+    float *mine = sweep_acc + (wave * rw) * wl + lv;
+    for (int k = 0; k < rw; ++k)
+        if (active) *reinterpret_cast<vec_t *>(mine + k * wl) = V::zero();
+    const float *xl = X + col0 + lv;
+    const float *xl2 = X2 + col0 + lv - int64_t(split) * ldx2;
+    const int b = sptr[label * kSweepSlots + slot], e = sptr[label * kSweepSlots + slot + 1];
+
+    auto load_cv = [&](int idx) -> int2 {
+        const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long *>(scv + idx));
+        return make_int2(static_cast<int>(raw), static_cast<int>(raw >> 32));
+    };
+    int cur = -1;                                               // row (of this wave's rw) held in `acc`
+    vec_t acc = V::zero();
+    int2 nxt = make_int2(0, 0);
+    if (b + lane < e) nxt = load_cv(b + lane);
+    for (int base = b; base < e; base += 64) {
+        const int2 me = nxt;
+        nxt = make_int2(0, 0);                                  // col 0 / row 0 / weight 0 for the padded tail
+        if (base + 64 + lane < e) nxt = load_cv(base + 64 + lane);
+        const int n = min(64, e - base);
+        for (int j0 = 0; j0 < n; j0 += U) {
+            vec_t x[U];
+            float v[U];
+            int ri[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned cx = static_cast<unsigned>(readlane_i(me.x, j0 + u));
+                v[u] = readlane_f(me.y, j0 + u);
+                ri[u] = static_cast<int>(cx >> kSweepRowShift);
+                const int c = static_cast<int>(cx & ((1u << kSweepRowShift) - 1u));
+                const float *src = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
+                x[u] = *reinterpret_cast<const vec_t *>(src);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + j0 + u < e) {
+                    if (ri[u] != cur) {
+                        if (cur >= 0 && active) *reinterpret_cast<vec_t *>(mine + cur * wl) = acc;
+                        cur = ri[u];
+                        acc = *reinterpret_cast<const vec_t *>(mine + cur * wl);
+                    }
+                    V::fma(acc, v[u], x[u]);
+                }
+            }
+        }
+    }
+    if (cur >= 0 && active) *reinterpret_cast<vec_t *>(mine + cur * wl) = acc;
+    if (active) {
+        for (int k = 0; k < rw; ++k) {
+            const int64_t row = int64_t(slot_base) + (int64_t(slot) * rw + k) * kSweepLabels + label;
+            *reinterpret_cast<vec_t *>(carry + row * ldc + col0 + lv) = *reinterpret_cast<const vec_t *>(mine + k * wl);
+        }
+    }
+}
+
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
 template <int VEC>
@@ -436,6 +539,26 @@ void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
 }
 
 template <int VEC>
+int launch_sweep(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
+                 float *carry, int64_t ldc, hipStream_t stream) {
+    constexpr int U = 8;
+    const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
+    const int wl = ((std::min(F, 64 * VEC) + VEC - 1) / VEC) * VEC;
+    const size_t lds = sizeof(float) * static_cast<size_t>(kSweepWaves) * b.sweep_rw * wl;   // <= 128 KB
+    static std::atomic<size_t> granted{48 * 1024};
+    if (lds > granted.load()) {
+        TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_sweep<VEC, U>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        granted.store(lds);
+    }
+    dim3 grid(kSweepLabels * (kSweepSlots / kSweepWaves), tiles);
+    k_spmm_sweep<VEC, U><<<grid, 64 * kSweepWaves, lds, stream>>>(b.sweep_cv, b.sweep_ptr, b.sweep_rw, X, ldx, X2, ldx2,
+                                                                 split, F, carry, ldc, b.sweep_slot_base);
+    TGCN_HIP_CHECK(hipGetLastError());
+    return TGCN_OK;
+}
+
+template <int VEC>
 int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
@@ -448,7 +571,7 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         const FixEntry *fix;
         int32_t n_fix;
     };
-    const bool all = VEC == 1 && blk.n_hot > 0;
+    const bool all = VEC == 1 && (blk.n_hot > 0 || blk.n_sweep > 0);
     const View b = all ? View{blk.items_all, blk.n_items_all, blk.fix_all, blk.n_fix_all}
                        : View{blk.items, blk.n_items, blk.fix, blk.n_fix};
     const int32_t *rowptr = blk.rowptr;
@@ -466,6 +589,15 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
             default: launch_hot<8>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream); break;
         }
         TGCN_HIP_CHECK(hipGetLastError());
+    }
+    if (VEC == 4 && blk.n_sweep > 0) {
+        // lanes own 1, 2 or 4 floats of a row: full wavefronts at the narrow layer-2 widths too
+        if (F <= 64)
+            TGCN_CHECK(launch_sweep<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
+        else if (F <= 128)
+            TGCN_CHECK(launch_sweep<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
+        else
+            TGCN_CHECK(launch_sweep<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
     }
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);

@@ -628,9 +628,12 @@ def test_config_c5_power_law_graph_h256(cuda):
         sel = tgt == r
         s, e = rp[r].item(), rp[r + 1].item()
         assert torch.equal(col[s:e].cpu(), src[sel])
-        assert (val[s:e].cpu().double() - nw[sel].double()).abs().max().item() <= 2e-6 * nw[sel].abs().max().item()
+        # a heavy row's weights all carry the factor deg[r]^-1/2, and the oracle (like the reference's
+        # scatter_add on the CPU) sums deg[r] sequentially in fp32 over ~10^5..10^6 terms: that sum, not the
+        # plan's pairwise one, is off by ~sqrt(n) ulp -- hence 1e-4 here instead of 2e-6 / 1e-5
+        assert (val[s:e].cpu().double() - nw[sel].double()).abs().max().item() <= 1e-4 * nw[sel].abs().max().item()
         want = (nw[sel].double().unsqueeze(1) * xc[src[sel].long()].double()).sum(0)
-        assert rel_err(y[r], want.float()) < TOL, r
+        assert rel_err(y[r], want.float()) < 1e-4, r
     del tgt, src, nw, xc, ref
     rows = torch.cat([deg.topk(6).indices, torch.randint(0, N, (150,), device=cuda, generator=gen)]).tolist()
     for r in rows:
@@ -1003,6 +1006,60 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
             plan.spmm(xd, bd, out=out[:, 4:4 + F])
             assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and bool((out[:, :4] == 7).all())
     plan.close(); plain.close()
+
+
+@pytest.mark.parametrize("n,n_hubs,weight,dup", [(20011, 40, 192, False), (9001, 33, 64, True), (30000, 600, 64, False)])
+def test_column_sweep_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_hubs, weight, dup):
+    """k_spmm_sweep: the long rows below the hot ones, accumulated in LDS while 8 x 32 workgroups walk the
+    column blocks.  Thresholds are lowered so that graphs of test size get the block (the defaults ask for
+    >= 256 such rows and >= 65 536 operand rows); checked against the oracle and against the same graph's
+    plan without it (TGCN_SWEEP=0) for every lane width of the sweep (1, 2, 4 floats per lane, several
+    column tiles), the transposed block of an asymmetric operator, split operands and strided results."""
+    gen = torch.Generator().manual_seed(n)
+    if n_hubs > 100:                                  # many mid-length rows: every wave slot gets several rows
+        srcs, dsts = [], []
+        for h in range(n_hubs):
+            others = torch.randint(0, n, (int(300 + 5 * (h % 97)),), generator=gen)
+            others = others[others != h]
+            srcs += [others, torch.full_like(others, h)]
+            dsts += [torch.full_like(others, h), others]
+        ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
+        w = torch.rand(ei.shape[1], generator=gen) + 0.05
+    else:
+        ei, w = _hub_graph(n, n_hubs, gen, dup)
+    monkeypatch.setenv("TGCN_ITEM_WEIGHT", str(weight))
+    monkeypatch.setenv("TGCN_SWEEP_MIN_ROWS", "1")
+    monkeypatch.setenv("TGCN_SWEEP_MIN_COLS", "1")
+    monkeypatch.setenv("TGCN_SWEEP_SHARE", "0")
+    plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    st = plan.stats()
+    assert st["sweep_rows"] >= 512 and st["sweep_rows"] % 512 == 0 and st["sweep_nnz"] > 0
+    if n_hubs > 100:
+        assert st["sweep_rows"] == 1024               # 600 rows -> two rows per wave slot (some slots hold one)
+    assert plan.query(_lib.Q_SWEEP_ROWS_T) >= 512 and not plan.symmetric
+    monkeypatch.setenv("TGCN_SWEEP", "0")
+    plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    assert plain.stats()["sweep_rows"] == 0
+    monkeypatch.delenv("TGCN_SWEEP")
+    for F in (200, 64, 8, 132, 260, 520, 100, 7):
+        x = torch.randn(n, F, generator=gen)
+        b = torch.randn(F, generator=gen)
+        xd, bd = x.to(cuda), b.to(cuda)
+        for transpose in (False, True):
+            ref = oracle_spmm(ei, w, n, x, None if transpose else b, transpose=transpose)
+            got = plan.spmm(xd, None if transpose else bd, transpose=transpose)
+            assert rel_err(got, ref) < TOL, (F, transpose)
+            assert rel_err(got, plain.spmm(xd, None if transpose else bd, transpose=transpose)) < TOL
+            assert torch.equal(got, plan.spmm(xd, None if transpose else bd, transpose=transpose))  # reproducible
+        if F % 4 == 0:
+            split = n // 3
+            hi = torch.randn(n, F, device=cuda)
+            hi[11:11 + n - split] = xd[split:]
+            got = plan.spmm(xd[:split].contiguous(), bd, x2=hi[11:11 + n - split])
+            assert torch.equal(got, plan.spmm(xd, bd))
+            out = torch.full((n, F + 8), 3.0, device=cuda)
+            plan.spmm(xd, bd, out=out[:, 4:4 + F])
+            assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and (out[:, :4] == 3).all() and (out[:, 4 + F:] == 3).all()
 
 
 @pytest.mark.parametrize("F", [200, 64, 32, 7])          # wide, sub-group (16 / 8 lanes per row) and scalar kernels
