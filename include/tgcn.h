@@ -84,6 +84,22 @@ int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
                          const int64_t *row, const int64_t *col, const float *val,
                          int with_transpose, int device, tgcn_stream stream, tgcn_plan **out);
 
+/* tgcn_gcn_norm -- the normalisation half of tgcn_plan_create on its own (PyG-1.6.3 gcn_norm as the
+ * reference runs it, models.py:11-20): for every node dis[n] = deg[n]^-1/2 (inf -> 0) with deg the weighted
+ * in-degree at the target incl. the self loop, and loop_w[n] = the weight of that loop (the last input loop's,
+ * else add_self_loops as 1.0 / 2.0; all zeros when add_self_loops = 0).  The normalised weight of edge e is
+ * then w[e] * (dis[src] * dis[dst]), the association tgcn_plan_create uses.  No counterpart in the single-
+ * device reference: the 1-D partition (pytextgcn_amd/sharded.py) calls it so that every rank can cut its own
+ * local operators out of the edge list WITHOUT building the whole-graph plan -- the edge list is walked in
+ * chunks (TGCN_NORM_CHUNK edges, default 2^25), scratch is O(chunk) + O(n_nodes); deterministic.
+ *   dis, loop_w   fp32 [n_nodes] device buffers (loop_w may be NULL)
+ * Allocates scratch and synchronises `stream` (one-off per graph, like tgcn_plan_create). */
+int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges,
+                  const int64_t *src, int64_t src_stride,
+                  const int64_t *dst, int64_t dst_stride,
+                  const float *w, int add_self_loops, float *dis, float *loop_w,
+                  int device, tgcn_stream stream);
+
 int tgcn_plan_destroy(tgcn_plan *plan);
 
 /* tgcn_plan_query -- integers describing a plan (host pointer `out`). */

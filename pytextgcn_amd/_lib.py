@@ -29,6 +29,8 @@ SIGNATURES = {
                                  POINTER(c_void_p)]),
     "tgcn_plan_create_coo": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_void_p, POINTER(c_void_p)]),
+    "tgcn_gcn_norm": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                              c_void_p, c_int, c_void_p]),
     "tgcn_plan_destroy": (c_int, [c_void_p]),
     "tgcn_plan_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "tgcn_plan_export": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

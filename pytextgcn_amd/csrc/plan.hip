@@ -107,6 +107,66 @@ __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t 
     }
 }
 
+// ---- tgcn_gcn_norm: the degree factors on their own, over the edge list in bounded chunks ------------
+// keys of one chunk of edges [lo, lo + n): dst << 32 | src, dropped entries (input self-loops when loops are
+// re-appended, out-of-range indices) get the key N << 32 and sort behind every real row
+__global__ void k_norm_keys(int64_t lo, int64_t n, const int64_t *__restrict__ src, int64_t ss,
+                            const int64_t *__restrict__ dst, int64_t ds, const float *__restrict__ w, int64_t N,
+                            int add_loops, uint64_t *__restrict__ keys, float *__restrict__ vals) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const uint64_t drop = static_cast<uint64_t>(N) << 32;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t s = src[(lo + i) * ss], d = dst[(lo + i) * ds];
+        const bool bad = s < 0 || s >= N || d < 0 || d >= N;
+        keys[i] = (bad || (add_loops && s == d)) ? drop : (static_cast<uint64_t>(d) << 32) | static_cast<uint64_t>(s);
+        vals[i] = w ? w[lo + i] : 1.0f;
+    }
+}
+
+// loop weight of every node (the last input loop's weight, else `fill`) and the start of its degree sum
+__global__ void k_norm_loops(int64_t N, int add_loops, float fill, const unsigned long long *__restrict__ loop_eid,
+                             const float *__restrict__ w, float *__restrict__ loop_w, double *__restrict__ deg) {
+    const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float lw = 0.f;
+    if (add_loops) {
+        const unsigned long long le = loop_eid[n];
+        lw = le ? (w ? w[le - 1] : 1.0f) : fill;
+    }
+    if (loop_w) loop_w[n] = lw;
+    deg[n] = static_cast<double>(lw);
+}
+
+// one wavefront per row of a sorted chunk: fp32 sum in a fixed lane order, added to the row's double
+__global__ void k_norm_deg(const int32_t *__restrict__ rowptr, const float *__restrict__ vals, int64_t N,
+                           double *__restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
+    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (b == e) continue;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int32_t j = b + lane;
+        for (; j + 7 * 64 < e; j += 8 * 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += vals[j + u * 64];
+        }
+        for (; j < e; j += 64) acc[0] += vals[j];
+        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) deg[r] += static_cast<double>(s);
+    }
+}
+
+__global__ void k_norm_dis(int64_t N, const double *__restrict__ deg, float *__restrict__ dis) {
+    const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float d = 1.0f / sqrtf(static_cast<float>(deg[n]));   // deg.pow(-0.5) on the fp32 degree
+    if (isinf(d)) d = 0.0f;                               // masked_fill_(== inf, 0)
+    dis[n] = d;
+}
+
 // rowptr[r] = first position whose key has row >= r
 __global__ void k_rowptr(const uint64_t *__restrict__ keys, int64_t nnz, int64_t N,
                          int32_t *__restrict__ rowptr) {
@@ -1022,6 +1082,80 @@ int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
         return st;
     }
     *out = plan;
+    return TGCN_OK;
+}
+
+int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t src_stride,
+                  const int64_t *dst, int64_t dst_stride, const float *w, int add_self_loops, float *dis,
+                  float *loop_w, int device, tgcn_stream stream_) {
+    using namespace tgcn;
+    if (n_nodes <= 0 || n_edges < 0 || !dis) {
+        set_error("tgcn_gcn_norm: need n_nodes > 0, n_edges >= 0 and a non-NULL dis");
+        return TGCN_E_INVALID;
+    }
+    if (n_edges > 0 && (!src || !dst || src_stride <= 0 || dst_stride <= 0)) {
+        set_error("tgcn_gcn_norm: src/dst must be non-NULL with positive strides");
+        return TGCN_E_INVALID;
+    }
+    if (n_nodes >= (int64_t(1) << 31) - 1) {
+        set_error("tgcn_gcn_norm: n_nodes=%lld exceeds the int32 index range of this build", (long long)n_nodes);
+        return TGCN_E_RANGE;
+    }
+    DeviceGuard guard;
+    TGCN_CHECK(guard.enter(device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t N = n_nodes, E = n_edges;
+    const int add_loops = std::max(0, std::min(add_self_loops, 2));
+    const char *cs = std::getenv("TGCN_NORM_CHUNK");
+    int64_t chunk = cs ? std::atoll(cs) : (int64_t(1) << 25);           // 32 M edges: 768 MB of sort scratch
+    chunk = std::max<int64_t>(1024, std::min<int64_t>(chunk, (int64_t(1) << 31) - 2));
+    const int64_t cap = std::min(chunk, std::max<int64_t>(E, 1));
+    DevBuf loop_eid, flags, keys_a, keys_b, vals_a, vals_b, rowptr, deg;
+    TGCN_CHECK(loop_eid.alloc(sizeof(unsigned long long) * (add_loops ? N : 1)));
+    TGCN_CHECK(flags.alloc(sizeof(unsigned int) * 4));
+    TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * cap));
+    TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * cap));
+    TGCN_CHECK(vals_a.alloc(sizeof(float) * cap));
+    TGCN_CHECK(vals_b.alloc(sizeof(float) * cap));
+    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(deg.alloc(sizeof(double) * N));
+    TGCN_HIP_CHECK(hipMemsetAsync(loop_eid.p, 0, loop_eid.bytes ? loop_eid.bytes : 16, stream));
+    TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
+    if (E > 0) {
+        k_scan_edges<<<grid_for(E, kThreads, 4096), kThreads, 0, stream>>>(
+            E, src, src_stride, dst, dst_stride, N, N, add_loops, loop_eid.as<unsigned long long>(),
+            flags.as<unsigned int>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    unsigned int h_flags[4] = {0, 0, 0, 0};
+    TGCN_HIP_CHECK(hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_flags[0]) {
+        set_error("an index lies outside [0, %lld)", (long long)N);
+        return TGCN_E_RANGE;
+    }
+    k_norm_loops<<<grid_for(N), kThreads, 0, stream>>>(N, add_loops, static_cast<float>(add_loops),
+                                                       loop_eid.as<unsigned long long>(), w, loop_w, deg.as<double>());
+    TGCN_HIP_CHECK(hipGetLastError());
+    unsigned node_bits = 1;
+    while ((int64_t(1) << node_bits) <= N) ++node_bits;
+    for (int64_t lo = 0; lo < E; lo += chunk) {
+        const int64_t n = std::min(chunk, E - lo);
+        k_norm_keys<<<grid_for(n, kThreads, 8192), kThreads, 0, stream>>>(lo, n, src, src_stride, dst, dst_stride, w,
+                                                                         N, add_loops, keys_a.as<uint64_t>(),
+                                                                         vals_a.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(), vals_b.as<float>(),
+                              n, 32 + node_bits, stream));
+        k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), n, N, rowptr.as<int32_t>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        k_norm_deg<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(rowptr.as<int32_t>(),
+                                                                                 vals_b.as<float>(), N, deg.as<double>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    k_norm_dis<<<grid_for(N), kThreads, 0, stream>>>(N, deg.as<double>(), dis);
+    TGCN_HIP_CHECK(hipGetLastError());
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));   // scratch is freed on return
     return TGCN_OK;
 }
 

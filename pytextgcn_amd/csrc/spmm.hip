@@ -403,20 +403,20 @@ __global__ __launch_bounds__(64 * kHotWaves) void k_spmm_hot(
 template <int VEC, int U>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
     const int2 *__restrict__ scv, const int32_t *__restrict__ sptr, int rw, const float *__restrict__ X,
-    int64_t ldx, const float *__restrict__ X2, int64_t ldx2, int split, int F, float *__restrict__ carry,
+    int64_t ldx, const float *__restrict__ X2, int64_t ldx2, int split, int F, int tw, float *__restrict__ carry,
     int64_t ldc, int slot_base) {
     using V = Vec<VEC>;
     using vec_t = typename V::type;
-    extern __shared__ __attribute__((aligned(16))) float sweep_acc[];   // [kSweepWaves * rw][wl]
+    extern __shared__ __attribute__((aligned(16))) float sweep_acc[];   // [kSweepWaves * rw][tw]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int label = blockIdx.x & (kSweepLabels - 1);
     const int slot = (blockIdx.x / kSweepLabels) * kSweepWaves + wave;
-    const int col0 = blockIdx.y * (64 * VEC);
-    const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;
+    const int col0 = blockIdx.y * tw;                           // column tile of tw <= 64 VEC floats (tw % VEC == 0)
+    const int nvec = (min(F - col0, tw) + VEC - 1) / VEC;
     const bool active = lane < nvec;
     const int lv = (active ? lane : nvec - 1) * VEC;            // idle lanes shadow the last vector, never store
-    const int wl = ((min(F, 64 * VEC) + VEC - 1) / VEC) * VEC;  // LDS row length: the widest tile's
+    const int wl = tw;                                          // LDS row length
     float *mine = sweep_acc + (wave * rw) * wl + lv;
     for (int k = 0; k < rw; ++k)
         if (active) *reinterpret_cast<vec_t *>(mine + k * wl) = V::zero();
@@ -538,22 +538,35 @@ void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
                                                        carry, ldc, b.hot_slot_base, b.hot_parts, b.n_hot);
 }
 
+// Column tiles of the sweep.  Narrow tiles are the point: the operand rows of the column blocks a label's
+// waves are spread over must sit in that XCD's 4 MB L2 at the same time, and the waves drift apart by several
+// blocks (nothing synchronises them); at <= 64 floats per tile the L2 holds >= 16 000 operand rows, and the LDS
+// partial sums shrink with the tile.  One dword per lane (VEC = 1), tiles run one after the other (grid.y).
+int sweep_vec_from_env() {
+    static const int v = [] {
+        const char *s = std::getenv("TGCN_SWEEP_VEC");
+        const int x = s ? std::atoi(s) : 1;
+        return (x == 1 || x == 2 || x == 4) ? x : 1;
+    }();
+    return v;
+}
+
 template <int VEC>
 int launch_sweep(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
                  float *carry, int64_t ldc, hipStream_t stream) {
     constexpr int U = 8;
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
-    const int wl = ((std::min(F, 64 * VEC) + VEC - 1) / VEC) * VEC;
-    const size_t lds = sizeof(float) * static_cast<size_t>(kSweepWaves) * b.sweep_rw * wl;   // <= 128 KB
+    const int tw = (((F + tiles - 1) / tiles) + 3) & ~3;       // equal tiles, multiple of 4 floats (16-byte pieces)
+    const size_t lds = sizeof(float) * static_cast<size_t>(kSweepWaves) * b.sweep_rw * tw;   // <= 128 KB
     static std::atomic<size_t> granted{48 * 1024};
     if (lds > granted.load()) {
         TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_sweep<VEC, U>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         granted.store(lds);
     }
-    dim3 grid(kSweepLabels * (kSweepSlots / kSweepWaves), tiles);
+    dim3 grid(kSweepLabels * (kSweepSlots / kSweepWaves), (F + tw - 1) / tw);
     k_spmm_sweep<VEC, U><<<grid, 64 * kSweepWaves, lds, stream>>>(b.sweep_cv, b.sweep_ptr, b.sweep_rw, X, ldx, X2, ldx2,
-                                                                 split, F, carry, ldc, b.sweep_slot_base);
+                                                                 split, F, tw, carry, ldc, b.sweep_slot_base);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }
@@ -591,13 +604,11 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         TGCN_HIP_CHECK(hipGetLastError());
     }
     if (VEC == 4 && blk.n_sweep > 0) {
-        // lanes own 1, 2 or 4 floats of a row: full wavefronts at the narrow layer-2 widths too
-        if (F <= 64)
-            TGCN_CHECK(launch_sweep<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
-        else if (F <= 128)
-            TGCN_CHECK(launch_sweep<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
-        else
-            TGCN_CHECK(launch_sweep<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream));
+        switch (sweep_vec_from_env()) {          // lanes own 1 float of a row (default); 2 / 4 for A/B runs
+            case 4: TGCN_CHECK(launch_sweep<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
+            case 2: TGCN_CHECK(launch_sweep<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
+            default: TGCN_CHECK(launch_sweep<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
+        }
     }
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);

@@ -42,17 +42,33 @@ from .conv import glorot_
 # partition + exchange logic under gloo without a GPU; the package itself ships no CPU engine.)
 # --------------------------------------------------------------------------------------------------
 class HipEngine:
-    def normalized_triplets(self, edge_index, edge_weight, num_nodes, add_self_loops, normalize,
-                            transpose) -> Tuple[Tensor, Tensor, Tensor, bool]:
-        """(row, col, val, symmetric) of M (or M^T), globally normalised, in CSR order."""
-        from .plan import GraphPlan
-        plan = GraphPlan(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
-        rp, col, val = plan.export_csr(transpose)
-        counts = (rp[1:] - rp[:-1]).long()
-        row = torch.repeat_interleave(torch.arange(num_nodes, device=rp.device), counts)
-        sym = plan.symmetric
-        plan.close()
-        return row, col.long(), val, sym
+    def gcn_norm(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+                 add_self_loops: int) -> Tuple[Tensor, Tensor]:
+        """(dis, loop_w): deg^-1/2 per node (in-degree at the target incl. the self loop, inf -> 0) and the
+        weight of every node's self loop, from the WHOLE edge list -- libtgcn.so `tgcn_gcn_norm`, which walks
+        the edges in bounded chunks: no whole-graph plan, no nnz-sized temporaries."""
+        import ctypes
+        from . import _lib
+        from .plan import _require_cuda, _stream_ptr
+        lib = _lib.load()
+        _require_cuda(edge_index, "edge_index")
+        if edge_index.dtype != torch.int64:
+            edge_index = edge_index.long()
+        dev = edge_index.device
+        n_edges = edge_index.size(1)
+        w = None
+        if edge_weight is not None:
+            w = edge_weight.detach().reshape(-1).float().contiguous()
+        dis = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        loop_w = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        src, dst = edge_index[0], edge_index[1]
+        with torch.cuda.device(dev):
+            _lib.check(lib.tgcn_gcn_norm(
+                num_nodes, n_edges, src.data_ptr() if n_edges else None, src.stride(0) if n_edges else 1,
+                dst.data_ptr() if n_edges else None, dst.stride(0) if n_edges else 1,
+                w.data_ptr() if w is not None else None, int(add_self_loops), dis.data_ptr(), loop_w.data_ptr(),
+                dev.index if dev.index is not None else torch.cuda.current_device(), _stream_ptr(dev)))
+        return dis, loop_w
 
     def make_op(self, row, col, val, n_rows, n_cols):
         from .plan import GraphPlan
@@ -73,6 +89,26 @@ class HipEngine:
     def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int, return_pred: bool = False):
         from .functional import masked_cross_entropy
         return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
+
+
+def _wrap64(v: int) -> int:
+    """A 64-bit constant as the signed value torch.int64 holds."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+_HASH_K = [tuple(_wrap64(k) for k in ks) for ks in (
+    (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0xFF51AFD7ED558CCD),
+    (0xD6E8FEB86659FD93, 0xA0761D6478BD642F, 0xE7037ED1A0B428DB, 0x8EBC6AF09C88C6E3))]
+
+
+def _entry_hash(r: Tensor, c: Tensor, vbits: Tensor, ks) -> int:
+    """Order-independent 64-bit fingerprint of a multiset of entries (r, c, bits(v)): the wrapping sum of a
+    mixed per-entry hash (int64 arithmetic wraps; integer sums are exact in any order)."""
+    x = r * ks[0] + c * ks[1] + vbits * ks[2]
+    x = torch.bitwise_xor(x, x >> 29) * ks[3]
+    x = torch.bitwise_xor(x, x >> 32)
+    return int(x.sum().item())
 
 
 class Partition:
@@ -133,9 +169,13 @@ class Partition:
 
 
 class ShardedGraph:
+    _CHUNK = 1 << 23      # edges per pass of the local-operator construction (transients stay O(chunk))
+
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                 group=None, hubs: Optional[Tensor] = None, add_self_loops: bool = True,
-                 normalize: bool = True, engine=None):
+                 group=None, hubs: Optional[Tensor] = None, add_self_loops=True,
+                 normalize: bool = True, engine=None, symmetric: Optional[bool] = None):
+        """`symmetric`: None = find out (an edge-multiset fingerprint of M against M^T); True / False skips
+        the test (TextGCN graphs are symmetric by construction, text2graph.py:148-171)."""
         self.group = group if group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
@@ -147,15 +187,21 @@ class ShardedGraph:
         self.hp, self.rp, self.n_local = part.hp, part.rp, part.n_local
         self.owned = part.owned(self.rank)
         self.real = self.owned >= 0
-        row, col, val, sym = self.engine.normalized_triplets(
-            edge_index, edge_weight, num_nodes, add_self_loops, normalize, False)
-        self.symmetric = bool(sym)
-        self.ops = [self._local_ops(row, col, val)]
+        # Normalisation over the WHOLE edge list (two vectors of N floats), then every rank cuts its own
+        # two operators out of the edge list chunk by chunk: no rank ever holds the whole-graph plan, its
+        # CSR or anything else of size nnz beyond the edge list it was handed.
+        # PyG adds the loops inside gcn_norm, so GCNConv(normalize=False) never sees them
+        loops = (max(0, min(int(add_self_loops), 2)) if normalize else 0)
+        self._dis = self._loop_w = None
+        if normalize:
+            self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops)
+        self._loops = loops
+        self.symmetric = bool(symmetric) if symmetric is not None else \
+            self._is_symmetric(edge_index, edge_weight)
+        self.ops = [self._local_ops(edge_index, edge_weight, transpose=False)]
         if not self.symmetric:
-            row, col, val, _ = self.engine.normalized_triplets(
-                edge_index, edge_weight, num_nodes, add_self_loops, normalize, True)
-            self.ops.append(self._local_ops(row, col, val))
-        del row, col, val
+            self.ops.append(self._local_ops(edge_index, edge_weight, transpose=True))
+        self._dis = self._loop_w = None
         self.plan = self.ops[0][1]            # the larger local operator (for reporting)
         # "collective": RCCL all-gather + reduce-scatter (default).  "p2p": the same exchange as direct
         # pairwise transfers (batched send/recv, all-to-all + local sum) -- on a full xGMI mesh every pair
@@ -177,22 +223,72 @@ class ShardedGraph:
         return cls(g.edge_index, g.edge_attr, n, group=group, hubs=hubs, **kw)
 
     # ---- construction ---------------------------------------------------------------------------
-    def _local_ops(self, t: Tensor, s: Tensor, w: Tensor):
-        """A_r and B_r from the global triplets M[t, s] = w."""
+    def _chunks(self, edge_index: Tensor, edge_weight: Optional[Tensor]):
+        """(source, target, w_hat) of the non-loop entries of M, a chunk of edges at a time: w_hat = w * (dis[s]
+        * dis[t]) -- the association of tgcn_plan_create, which keeps a symmetric graph bitwise symmetric."""
+        E = edge_index.size(1)
+        for lo in range(0, E, self._CHUNK):
+            hi = min(E, lo + self._CHUNK)
+            s, t = edge_index[0, lo:hi], edge_index[1, lo:hi]
+            w = edge_weight[lo:hi].float() if edge_weight is not None else \
+                torch.ones(hi - lo, dtype=torch.float32, device=edge_index.device)
+            if self._loops:                                    # input loops are replaced (add_remaining_self_loops)
+                keep = s != t
+                s, t, w = s[keep], t[keep], w[keep]
+            if self._dis is not None:
+                w = w * (self._dis[s] * self._dis[t])
+            yield s, t, w
+
+    def _is_symmetric(self, edge_index: Tensor, edge_weight: Optional[Tensor]) -> bool:
+        """M == M^T as edge multisets {(target, source, bits(w_hat))}: two independent 64-bit fingerprints of
+        the entries against those of the swapped entries (the loops are symmetric by construction).  Equal
+        multisets give equal operators up to the order duplicates are summed in."""
+        sums = [[0, 0], [0, 0]]
+        for s, t, w in self._chunks(edge_index, edge_weight):
+            bits = w.view(torch.int32).long()
+            for i, ks in enumerate(_HASH_K):
+                sums[i][0] = (sums[i][0] + _entry_hash(t, s, bits, ks)) & ((1 << 64) - 1)
+                sums[i][1] = (sums[i][1] + _entry_hash(s, t, bits, ks)) & ((1 << 64) - 1)
+        return all(a == b for a, b in sums)
+
+    def _local_ops(self, edge_index: Tensor, edge_weight: Optional[Tensor], transpose: bool):
+        """A_r and B_r of M (or of M^T), cut out of the edge list chunk by chunk."""
         p, r, W, hp, rp = self.part, self.rank, self.world, self.hp, self.rp
-        t_hub, s_hub = p.hub_mask[t], p.hub_mask[s]
-        t_mine, s_mine = p.owner[t] == r, p.owner[s] == r
-        # A: hub rows (gathered numbering) <- own regular columns
-        a = t_hub & ~s_hub & s_mine
+        dev = edge_index.device
+        parts_a, parts_b = [], []
+        for s, t, w in self._chunks(edge_index, edge_weight):
+            if transpose:
+                s, t = t, s
+            t_hub, s_hub = p.hub_mask[t], p.hub_mask[s]
+            t_mine, s_mine = p.owner[t] == r, p.owner[s] == r
+            # A: hub rows (gathered numbering) <- own regular columns
+            if rp > 0:
+                a = t_hub & ~s_hub & s_mine
+                parts_a.append((p.hub_col[t[a]], p.slot[s[a]], w[a]))
+            # B: own rows <- all hubs + own regular columns (hub <- regular entries all live in A)
+            b = t_mine & (s_hub | (s_mine & ~t_hub))
+            tb, sb = t[b], s[b]
+            parts_b.append((torch.where(p.hub_mask[tb], p.slot[tb], hp + p.slot[tb]),
+                            torch.where(p.hub_mask[sb], p.hub_col[sb], p.reg_col[sb]), w[b]))
+        if self._loops:
+            # one loop per own node, after the edges (the tail position add_remaining_self_loops gives them)
+            own = self.owned[self.real]
+            lrow = torch.nonzero(self.real).flatten()
+            lcol = torch.where(p.hub_mask[own], p.hub_col[own], p.reg_col[own])
+            lw = self._loop_w[own]
+            if self._dis is not None:
+                lw = lw * (self._dis[own] * self._dis[own])
+            parts_b.append((lrow, lcol, lw))
+
+        def cat(parts, k):
+            if not parts:
+                return torch.empty(0, dtype=torch.float32 if k == 2 else torch.int64, device=dev)
+            return torch.cat([q[k] for q in parts])
         A = None
         if rp > 0:
-            A = self.engine.make_op(p.hub_col[t[a]], p.slot[s[a]], w[a], W * hp, rp)
-        # B: own rows <- all hubs + own regular columns (hub <- regular entries all live in A)
-        b = t_mine & (s_hub | (s_mine & ~t_hub))
-        tb, sb = t[b], s[b]
-        brow = torch.where(p.hub_mask[tb], p.slot[tb], hp + p.slot[tb])
-        bcol = torch.where(p.hub_mask[sb], p.hub_col[sb], p.reg_col[sb])
-        B = self.engine.make_op(brow, bcol, w[b], hp + rp, W * hp + rp)
+            A = self.engine.make_op(cat(parts_a, 0), cat(parts_a, 1), cat(parts_a, 2), W * hp, rp)
+        del parts_a
+        B = self.engine.make_op(cat(parts_b, 0), cat(parts_b, 1), cat(parts_b, 2), hp + rp, W * hp + rp)
         return A, B
 
     # ---- data movement ---------------------------------------------------------------------------

@@ -29,15 +29,20 @@ class _OracleOp:
 
 
 class OracleEngine:
-    def normalized_triplets(self, edge_index, edge_weight, num_nodes, add_self_loops, normalize, transpose):
-        tgt, src, w = O.normalized_coo(edge_index, edge_weight, num_nodes, add_self_loops)
-        key_a = torch.argsort(tgt * num_nodes + src, stable=True)
-        key_b = torch.argsort(src * num_nodes + tgt, stable=True)
-        sym = bool(torch.equal(tgt[key_a], src[key_b]) and torch.equal(src[key_a], tgt[key_b])
-                   and torch.allclose(w[key_a], w[key_b], rtol=1e-6))
-        if transpose:
-            tgt, src = src, tgt
-        return tgt, src, w, sym
+    def gcn_norm(self, edge_index, edge_weight, num_nodes, add_self_loops):
+        """(deg^-1/2, loop weight) per node, from the oracle's add_remaining_self_loops + degree sum."""
+        w = edge_weight if edge_weight is not None else torch.ones(edge_index.size(1))
+        fill = float(add_self_loops)
+        loop_w = torch.zeros(num_nodes)
+        if add_self_loops:
+            ei, w = O.add_remaining_self_loops(edge_index, w, fill, num_nodes)
+            loop_w = w[-num_nodes:].clone()
+        else:
+            ei = edge_index
+        deg = torch.zeros(num_nodes).index_add_(0, ei[1], w)
+        dis = deg.pow(-0.5)
+        dis[dis == float("inf")] = 0
+        return dis, loop_w
 
     def make_op(self, row, col, val, n_rows, n_cols):
         return _OracleOp(row, col, val, n_rows, n_cols)
