@@ -340,22 +340,26 @@ __global__ void k_hot_fill(const int32_t *__restrict__ hot_rows, const int32_t *
 }
 
 // Column-sweep block: sort keys of the entries of the swept rows.  Row m of the list (blockIdx.y) is CSR
-// row srow[m], local row sli[m] = slot * rw + row_in_slot; entry j of it goes to position soff[m] + (j -
-// rowptr[row]).  Key = (label * 512 + slot) << 32 | (block >> 3) << 14 | row_in_slot << 11 | column % 2048
+// row srow[m], cut into spieces[m] interleaved PIECES (entry j of the row belongs to piece j mod k: every piece
+// spans all columns); piece q is local row piece_li[spbase[m] + q] = slot * rw + row_in_slot.  Entry j goes
+// to position soff[m] + (j - rowptr[row]).  Key = (label * 512 + slot) << 32 | (block >> 3) << 14 | row_in_slot << 11 | column % 2048
 // with block = column / 2048 and label = block % 8: after a stable sort every (label, slot) owns one
 // contiguous run ordered by column block, then row, then column (ties: storage order).
 constexpr int kSweepBlockBits = 11;    // 2048 operand rows per column block (1.6 MB at F = 200)
 
-__global__ void k_sweep_keys(const int32_t *__restrict__ srow, const int32_t *__restrict__ sli,
+__global__ void k_sweep_keys(const int32_t *__restrict__ srow, const int32_t *__restrict__ spieces,
+                             const int32_t *__restrict__ spbase, const int32_t *__restrict__ piece_li,
                              const int64_t *__restrict__ soff, int rw, const int32_t *__restrict__ rowptr,
                              const int2 *__restrict__ cv, uint64_t *__restrict__ keys, float *__restrict__ vals) {
     const int m = blockIdx.y;
-    const int32_t r = srow[m], li = sli[m];
-    const uint32_t slot = static_cast<uint32_t>(li / rw), ris = static_cast<uint32_t>(li % rw);
+    const int32_t r = srow[m], k = spieces[m];
+    const int32_t *li_of = piece_li + spbase[m];
     const int32_t b = rowptr[r], e = rowptr[r + 1];
     const int64_t o = soff[m];
     for (int32_t j = b + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
         const int2 p = cv[j];
+        const int32_t li = li_of[(j - b) % k];             // entry j of the row belongs to piece j mod k
+        const uint32_t slot = static_cast<uint32_t>(li / rw), ris = static_cast<uint32_t>(li % rw);
         const uint32_t c = static_cast<uint32_t>(p.x), blk = c >> kSweepBlockBits;
         const uint64_t hi = (blk & 7u) * kSweepSlots + slot;
         const uint32_t lo = ((blk >> 3) << 14) | (ris << kSweepBlockBits) | (c & ((1u << kSweepBlockBits) - 1u));
@@ -404,7 +408,9 @@ Knobs knobs_from_env() {
     k.hot_rows = geti("TGCN_HOT_ROWS", 1);
     const char *hr = std::getenv("TGCN_HOT_RATIO");
     k.hot_ratio = hr ? std::atof(hr) : 2.0;
-    k.sweep_rows = geti("TGCN_SWEEP", 1) ? std::min(geti("TGCN_SWEEP_ROWS", 4096), kSweepSlots * 8) : 0;
+    // opt-in (TGCN_SWEEP=1): on config c4 the block moves 10 GB of fabric traffic out of the gather kernel but
+    // costs as much time as it saves (persistent waves drift apart further than the 4 MB an L2 holds)
+    k.sweep_rows = geti("TGCN_SWEEP", 0) ? std::min(geti("TGCN_SWEEP_ROWS", 4096), kSweepSlots * 8) : 0;
     k.sweep_min_rows = std::max(1, geti("TGCN_SWEEP_MIN_ROWS", 256));
     const char *ss = std::getenv("TGCN_SWEEP_SHARE");
     k.sweep_share = ss ? std::atof(ss) : 0.05;
@@ -431,6 +437,7 @@ void free_block(CsrBlock &b) {
     if (b.hot_vals) (void)hipFree(b.hot_vals);
     if (b.sweep_cv) (void)hipFree(b.sweep_cv);
     if (b.sweep_ptr) (void)hipFree(b.sweep_ptr);
+    if (b.sweep_out) (void)hipFree(b.sweep_out);
     b = CsrBlock{};
 }
 
@@ -577,8 +584,9 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
     // sums in LDS and walk the COLUMNS instead -- label x (one per XCD) takes column blocks b = x (mod 8) in
     // ascending order, so the 2048 operand rows of a block cross the fabric once, into ONE L2, and serve every
     // swept row from there.
-    std::vector<int32_t> sweep_of_long(static_cast<size_t>(n_long), -1);   // long-row index -> local row
-    int32_t n_sweep = 0, sweep_rw = 0, n_swept = 0;
+    std::vector<int32_t> sweep_of_long(static_cast<size_t>(n_long), -1);   // long-row index -> first carry row
+    std::vector<int32_t> sweep_pieces(static_cast<size_t>(n_long), 0);    // ... and pieces of that row
+    int32_t n_sweep = 0, sweep_rw = 0, sweep_carry_rows = 0;
     if (kn.sweep_rows > 0 && n_long > 0 && b.n_cols >= kn.sweep_min_cols &&
         b.n_cols < (int64_t(1) << kSweepRowShift)) {
         std::vector<int32_t> cand;
@@ -586,41 +594,76 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         for (int32_t i = 0; i < n_long; ++i)
             if (hot_of_long[i] < 0) cand.push_back(i);
         auto deg = [&](int32_t i) { return rp[long_rows[i] + 1] - rp[long_rows[i]]; };
-        const size_t take = std::min<size_t>(cand.size(), static_cast<size_t>(kn.sweep_rows));
-        std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [&](int32_t x, int32_t y) {
+        std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) {
             return deg(x) != deg(y) ? deg(x) > deg(y) : x < y;
         });
-        int64_t total = 0;
-        for (size_t q = 0; q < take; ++q) total += deg(cand[q]);
+        // A wave slot owns up to 8 local rows and all slots must carry the same number of entries (the
+        // kernel runs as long as its fullest slot), so a row heavier than twice the mean local row is cut
+        // into k interleaved pieces that become local rows of their own (their partial sums are added by
+        // k_spmm_fix like every other partial).  Take as many of the longest rows as then fit 4096 local rows.
+        const int32_t capacity = std::min(kn.sweep_rows, kSweepSlots * 8);
+        size_t take = std::min<size_t>(cand.size(), static_cast<size_t>(capacity));
+        int64_t total = 0, cap = 0, n_local = 0;
+        while (take > 0) {
+            total = 0;
+            for (size_t q = 0; q < take; ++q) total += deg(cand[q]);
+            cap = std::max<int64_t>(64, (2 * total + capacity - 1) / capacity);
+            n_local = 0;
+            for (size_t q = 0; q < take; ++q) n_local += (deg(cand[q]) + cap - 1) / cap;
+            if (n_local <= capacity) break;
+            take = take * 7 / 8;
+        }
         size_t free_b = 0, total_b = 0;
         const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
                           static_cast<size_t>(total) * 32 + (size_t(1) << 30) < free_b;
         (void)hipGetLastError();
-        if (static_cast<int64_t>(take) >= kn.sweep_min_rows && fits &&
+        if (take > 0 && static_cast<int64_t>(take) >= kn.sweep_min_rows && fits &&
             static_cast<double>(total) >= kn.sweep_share * static_cast<double>(b.nnz)) {
-            sweep_rw = static_cast<int32_t>((take + kSweepSlots - 1) / kSweepSlots);
+            sweep_rw = static_cast<int32_t>((n_local + kSweepSlots - 1) / kSweepSlots);
             n_sweep = sweep_rw * kSweepSlots;
-            n_swept = static_cast<int32_t>(take);
-            // rows in degree order are dealt to the 512 wave slots in snake order: every slot (and so
-            // every workgroup) gets the same share of the entries
-            std::vector<int32_t> srow(take), sli(take);
+            // local rows (row pieces), heaviest first, each to the slot that is lightest so far and has room
+            struct Piece {
+                int32_t m, q, size;
+            };
+            std::vector<Piece> pieces;
+            pieces.reserve(static_cast<size_t>(n_local));
+            std::vector<int32_t> srow(take), spieces(take), spbase(take);
             std::vector<int64_t> soff(take);
             int64_t off = 0;
-            int32_t max_deg = 0;
-            for (size_t q = 0; q < take; ++q) {
-                const int32_t round = static_cast<int32_t>(q / kSweepSlots), j = static_cast<int32_t>(q % kSweepSlots);
-                const int32_t slot = (round & 1) ? kSweepSlots - 1 - j : j;
-                const int32_t li = slot * sweep_rw + round;
-                sweep_of_long[cand[q]] = li;
-                srow[q] = long_rows[cand[q]];
-                sli[q] = li;
-                soff[q] = off;
-                off += deg(cand[q]);
-                max_deg = std::max(max_deg, deg(cand[q]));
+            int32_t max_deg = 0, pb = 0;
+            for (size_t m = 0; m < take; ++m) {
+                const int32_t d = deg(cand[m]), k = static_cast<int32_t>((d + cap - 1) / cap);
+                srow[m] = long_rows[cand[m]];
+                spieces[m] = k;
+                spbase[m] = pb;
+                soff[m] = off;
+                for (int32_t q = 0; q < k; ++q) pieces.push_back({static_cast<int32_t>(m), q, (d - q + k - 1) / k});
+                sweep_of_long[cand[m]] = pb * kSweepLabels;          // carry rows [8 pb, 8 (pb + k)) of the block
+                sweep_pieces[cand[m]] = k;
+                pb += k;
+                off += d;
+                max_deg = std::max(max_deg, d);
             }
-            DevBuf d_row, d_li, d_off, keys_a, keys_b, vals_a, vals_b, d_scv, d_ptr;
+            sweep_carry_rows = pb * kSweepLabels;
+            std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.size > y.size; });
+            std::vector<int64_t> load(kSweepSlots, 0);
+            std::vector<int32_t> count(kSweepSlots, 0), piece_li(static_cast<size_t>(n_local), 0);
+            std::vector<int32_t> out_row(static_cast<size_t>(n_sweep), -1);   // local row -> carry row of its label 0
+            for (const Piece &pc : pieces) {
+                int best = -1;
+                for (int sl = 0; sl < kSweepSlots; ++sl)
+                    if (count[sl] < sweep_rw && (best < 0 || load[sl] < load[best])) best = sl;
+                const int32_t li = best * sweep_rw + count[best];
+                ++count[best];
+                load[best] += pc.size;
+                piece_li[spbase[pc.m] + pc.q] = li;
+                out_row[li] = (spbase[pc.m] + pc.q) * kSweepLabels;
+            }
+            DevBuf d_row, d_pieces, d_pbase, d_pli, d_off, keys_a, keys_b, vals_a, vals_b, d_scv, d_ptr, d_out;
             TGCN_CHECK(d_row.alloc(sizeof(int32_t) * take));
-            TGCN_CHECK(d_li.alloc(sizeof(int32_t) * take));
+            TGCN_CHECK(d_pieces.alloc(sizeof(int32_t) * take));
+            TGCN_CHECK(d_pbase.alloc(sizeof(int32_t) * take));
+            TGCN_CHECK(d_pli.alloc(sizeof(int32_t) * piece_li.size()));
             TGCN_CHECK(d_off.alloc(sizeof(int64_t) * take));
             TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
             TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
@@ -628,14 +671,21 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
             TGCN_CHECK(d_scv.alloc(sizeof(int2) * total));
             TGCN_CHECK(d_ptr.alloc(sizeof(int32_t) * (kSweepLabels * kSweepSlots + 1)));
-            TGCN_HIP_CHECK(hipMemcpyAsync(d_row.p, srow.data(), sizeof(int32_t) * take, hipMemcpyHostToDevice, stream));
-            TGCN_HIP_CHECK(hipMemcpyAsync(d_li.p, sli.data(), sizeof(int32_t) * take, hipMemcpyHostToDevice, stream));
-            TGCN_HIP_CHECK(hipMemcpyAsync(d_off.p, soff.data(), sizeof(int64_t) * take, hipMemcpyHostToDevice, stream));
+            TGCN_CHECK(d_out.alloc(sizeof(int32_t) * out_row.size()));
+            auto h2d = [&](DevBuf &d, const void *src, size_t bytes) {
+                return hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, stream);
+            };
+            TGCN_HIP_CHECK(h2d(d_row, srow.data(), sizeof(int32_t) * take));
+            TGCN_HIP_CHECK(h2d(d_pieces, spieces.data(), sizeof(int32_t) * take));
+            TGCN_HIP_CHECK(h2d(d_pbase, spbase.data(), sizeof(int32_t) * take));
+            TGCN_HIP_CHECK(h2d(d_pli, piece_li.data(), sizeof(int32_t) * piece_li.size()));
+            TGCN_HIP_CHECK(h2d(d_off, soff.data(), sizeof(int64_t) * take));
+            TGCN_HIP_CHECK(h2d(d_out, out_row.data(), sizeof(int32_t) * out_row.size()));
             dim3 grid(static_cast<unsigned>(std::min<int64_t>((max_deg + kThreads - 1) / kThreads, 256)),
                       static_cast<unsigned>(take));
-            k_sweep_keys<<<grid, kThreads, 0, stream>>>(d_row.as<int32_t>(), d_li.as<int32_t>(), d_off.as<int64_t>(),
-                                                        sweep_rw, b.rowptr, b.cv, keys_a.as<uint64_t>(),
-                                                        vals_a.as<float>());
+            k_sweep_keys<<<grid, kThreads, 0, stream>>>(d_row.as<int32_t>(), d_pieces.as<int32_t>(), d_pbase.as<int32_t>(),
+                                                        d_pli.as<int32_t>(), d_off.as<int64_t>(), sweep_rw, b.rowptr, b.cv,
+                                                        keys_a.as<uint64_t>(), vals_a.as<float>());
             TGCN_HIP_CHECK(hipGetLastError());
             TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
                                   vals_b.as<float>(), total, 32 + 12, stream));   // syncs: host vectors done
@@ -649,12 +699,15 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             b.n_sweep = n_sweep;
             b.sweep_rw = sweep_rw;
             b.sweep_nnz = total;
-            b.bytes += d_scv.bytes + d_ptr.bytes;
+            b.bytes += d_scv.bytes + d_ptr.bytes + d_out.bytes;
             b.sweep_cv = static_cast<int2 *>(d_scv.release());
             b.sweep_ptr = static_cast<int32_t *>(d_ptr.release());
+            b.sweep_out = static_cast<int32_t *>(d_out.release());
+        } else {
+            std::fill(sweep_of_long.begin(), sweep_of_long.end(), -1);
         }
     }
-    (void)n_swept;
+
 
     // pass 2: segments of the long rows, launch order, fix list.  Built once for the complete operator
     // and, when there is a hot block, once more without the hot rows (the list the float4 kernels use
@@ -718,13 +771,13 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             for (int32_t k = 0; k < n_hot; ++k)
                 fix.push_back({hot_rows[k], static_cast<int32_t>(slots + int64_t(k) * b.hot_parts), b.hot_parts, 0});
             slots += int64_t(n_hot) * b.hot_parts;
-            // swept row with local index li: one partial per label, carry rows [base + 8 li, base + 8 li + 8)
+            // swept row cut into k pieces: one partial per piece and label, carry rows [base + first, + 8 k)
             out.sweep_slot_base = static_cast<int32_t>(slots);
             for (int32_t i = 0; i < n_long; ++i)
                 if (sweep_of_long[i] >= 0)
-                    fix.push_back({long_rows[i], static_cast<int32_t>(slots + int64_t(sweep_of_long[i]) * kSweepLabels),
-                                   kSweepLabels, 0});
-            slots += int64_t(n_sweep) * kSweepLabels;
+                    fix.push_back({long_rows[i], static_cast<int32_t>(slots + sweep_of_long[i]),
+                                   sweep_pieces[i] * kSweepLabels, 0});
+            slots += sweep_carry_rows;
         }
         if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) overflow = true;
         out.slots = slots;

@@ -298,6 +298,108 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
     }
 }
 
+// Narrow rows, buffer-addressed form (the common case: one operand buffer below 4 GB).  Same work split as
+// k_spmm_sub; what changes is the cost of an entry.  The PMC profile of k_spmm_sub on c4, F = 64
+// (profiles/r02a_pmc_c4_f64_before_sweep.md) shows 19.5 vector-ALU instructions per gather instruction and the
+// VALU busy 66 % of the time: 64-bit address arithmetic, the split-operand select and the lane-index arithmetic
+// of ds_bpermute, per entry.  Here
+//   * the lane that loads a (col, val) pair turns the column into a 32-bit BYTE OFFSET once (one multiply per
+//     16 entries instead of one 64-bit multiply-add per gather); padding lanes get an offset beyond the buffer;
+//   * a gather is `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`: the hardware adds the base, and an offset
+//     outside the buffer returns zeros without touching memory -- padding needs no mask (0 * 0, never 0 * inf);
+//   * the ds_bpermute source lane is a constant of the unrolled loop (folded into the instruction's offset);
+//   * the four FMAs of an entry are two packed ones (v_pk_fma_f32).
+typedef float pk_f2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOobOffset = 0xFFFFFF00u;   // beyond any buffer this kernel is launched on (< 0xFFFF0000 bytes)
+
+template <int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_subb(
+    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const int2 *__restrict__ cv, const float *__restrict__ X, unsigned ldx4 /* row stride in bytes */,
+    unsigned x_bytes, int F, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy,
+    float *__restrict__ carry, int64_t ldc) {
+    constexpr int S = 64 / G;
+    static_assert(G % U == 0, "a batch of G entries is gathered in whole groups of U");
+    const int lane = threadIdx.x & 63;
+    const int item_id =
+        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item_id >= n_items) return;
+    const int sub = lane / G, sl = lane % G;
+    const int nvec = F / 4;                                    // <= G (checked by the launcher)
+    const bool active = sl < nvec;
+    const unsigned lane_off = static_cast<unsigned>((active ? sl : nvec - 1) * 16);
+    const WorkItem it = items[item_id];
+    const bool segment = it.row_end < 0;
+    float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bvec = *reinterpret_cast<const float4 *>(bias + lane_off / 4);
+    // the descriptor is built from kernel arguments only: wave-uniform by construction (no waterfall loop)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(X), /*stride*/ static_cast<short>(0), static_cast<int>(x_bytes), 0x00020000);
+    const int bp_base = (sub * G) * 4;                         // ds_bpermute address of this sub-group's lane 0
+
+    // sum over entries start, start + stride, ... < end (per sub-group values)
+    auto run = [&](int start, int stride, int end) -> float4 {
+        pk_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int t0 = start; t0 < end; t0 += G * stride) {
+            const int my = t0 + sl * stride;
+            int2 e = cv[min(my, end - 1)];                     // unconditional load, clamped index
+            unsigned off = static_cast<unsigned>(e.x) * ldx4;  // byte offset of the operand row
+            if (my >= end) {                                   // padding: no memory access, zero operand, zero weight
+                off = kOobOffset;
+                e.y = 0;
+            }
+            const int nb = min(G, (end - t0 + stride - 1) / stride);
+#pragma unroll
+            for (int u0 = 0; u0 < G; u0 += U) {
+                if (u0 >= nb) break;
+                float4 x[U];
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int src = bp_base + (u0 + u) * 4;
+                    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(off)));
+                    v[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, e.y));
+                    // + this lane's 16 bytes of the row (a padding offset stays beyond the buffer: no wrap)
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(o + lane_off), 0, 0);
+                    x[u] = make_float4(__int_as_float(raw[0]), __int_as_float(raw[1]), __int_as_float(raw[2]),
+                                       __int_as_float(raw[3]));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const pk_f2 vv = {v[u], v[u]};
+                    const pk_f2 x01 = {x[u].x, x[u].y}, x23 = {x[u].z, x[u].w};
+                    a01 = __builtin_elementwise_fma(vv, x01, a01);
+                    a23 = __builtin_elementwise_fma(vv, x23, a23);
+                }
+            }
+        }
+        return make_float4(a01[0], a01[1], a23[0], a23[1]);
+    };
+
+    if (segment) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it.nnz_begin + sub < it.nnz_end) acc = run(it.nnz_begin + sub, S, it.nnz_end);
+#pragma unroll
+        for (int off = G; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        const int slot = -it.row_end - 1;
+        if (sub == 0 && active) *reinterpret_cast<float4 *>(carry + int64_t(slot) * ldc + lane_off / 4) = acc;
+    } else {
+        for (int r = it.row_begin + sub; r < it.row_end; r += S) {
+            const int b = rowptr[r], e = rowptr[r + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < e) acc = run(b, 1, e);
+            if (active)
+                *reinterpret_cast<float4 *>(Y + int64_t(r) * ldy + lane_off / 4) =
+                    make_float4(acc.x + bvec.x, acc.y + bvec.y, acc.z + bvec.z, acc.w + bvec.w);
+        }
+    }
+}
+
 // Dense hot block.  part[k][:] = sum over the columns c of this workgroup of vd[c][k] * X[c][:] for the
 // 32 hot rows k (plan.hip: build_items), as v_mfma_f32_32x32x2_f32 products: per step a wave takes two
 // consecutive columns c, c+1 -- the A fragment is 64 consecutive floats of vd (hot index = lane % 32,
@@ -404,7 +506,7 @@ template <int VEC, int U>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
     const int2 *__restrict__ scv, const int32_t *__restrict__ sptr, int rw, const float *__restrict__ X,
     int64_t ldx, const float *__restrict__ X2, int64_t ldx2, int split, int F, int tw, float *__restrict__ carry,
-    int64_t ldc, int slot_base) {
+    int64_t ldc, int slot_base, const int32_t *__restrict__ out_row) {
     using V = Vec<VEC>;
     using vec_t = typename V::type;
     extern __shared__ __attribute__((aligned(16))) float sweep_acc[];   // [kSweepWaves * rw][tw]
@@ -466,7 +568,9 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
     if (cur >= 0 && active) *reinterpret_cast<vec_t *>(mine + cur * wl) = acc;
     if (active) {
         for (int k = 0; k < rw; ++k) {
-            const int64_t row = int64_t(slot_base) + (int64_t(slot) * rw + k) * kSweepLabels + label;
+            const int o = out_row[slot * rw + k];               // -1: this slot holds fewer than rw rows
+            if (o < 0) continue;
+            const int64_t row = int64_t(slot_base) + o + label;
             *reinterpret_cast<vec_t *>(carry + row * ldc + col0 + lv) = *reinterpret_cast<const vec_t *>(mine + k * wl);
         }
     }
@@ -530,6 +634,14 @@ bool narrow_from_env() {
     return on;
 }
 
+bool narrow_buf_from_env() {
+    static const bool on = [] {
+        const char *s = std::getenv("TGCN_SPMM_NARROW_BUF");
+        return s ? std::atoi(s) != 0 : true;
+    }();
+    return on;
+}
+
 template <int NT>
 void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
                 float *carry, int64_t ldc, hipStream_t stream) {
@@ -538,15 +650,15 @@ void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
                                                        carry, ldc, b.hot_slot_base, b.hot_parts, b.n_hot);
 }
 
-// Column tiles of the sweep.  Narrow tiles are the point: the operand rows of the column blocks a label's
-// waves are spread over must sit in that XCD's 4 MB L2 at the same time, and the waves drift apart by several
-// blocks (nothing synchronises them); at <= 64 floats per tile the L2 holds >= 16 000 operand rows, and the LDS
-// partial sums shrink with the tile.  One dword per lane (VEC = 1), tiles run one after the other (grid.y).
+// Column tiles of the sweep: 64 VEC floats wide at most, equal widths, run one after the other (grid.y).
+// TGCN_SWEEP_VEC = 1 / 2 / 4 floats per lane (A/B knob).  Narrow tiles were tried as a way to keep more operand
+// rows in the 4 MB L2 while the waves of a label drift apart (at 64 floats per tile it holds 16 000 rows): the hit
+// rate did not move (41 % against 43 %) and four passes cost more than they save.
 int sweep_vec_from_env() {
     static const int v = [] {
         const char *s = std::getenv("TGCN_SWEEP_VEC");
-        const int x = s ? std::atoi(s) : 1;
-        return (x == 1 || x == 2 || x == 4) ? x : 1;
+        const int x = s ? std::atoi(s) : 4;
+        return (x == 1 || x == 2 || x == 4) ? x : 4;
     }();
     return v;
 }
@@ -566,7 +678,7 @@ int launch_sweep(const CsrBlock &b, const float *X, int64_t ldx, const float *X2
     }
     dim3 grid(kSweepLabels * (kSweepSlots / kSweepWaves), (F + tw - 1) / tw);
     k_spmm_sweep<VEC, U><<<grid, 64 * kSweepWaves, lds, stream>>>(b.sweep_cv, b.sweep_ptr, b.sweep_rw, X, ldx, X2, ldx2,
-                                                                 split, F, tw, carry, ldc, b.sweep_slot_base);
+                                                                 split, F, tw, carry, ldc, b.sweep_slot_base, b.sweep_out);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }
@@ -604,7 +716,10 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         TGCN_HIP_CHECK(hipGetLastError());
     }
     if (VEC == 4 && blk.n_sweep > 0) {
-        switch (sweep_vec_from_env()) {          // lanes own 1 float of a row (default); 2 / 4 for A/B runs
+        // lanes own 4 floats of a row (measured best on c4: 1.0 ms against 1.7 ms for one float per lane in
+        // four narrow column tiles); narrow widths always take one float per lane (full wavefronts at F <= 64)
+        const int v = F <= 64 ? 1 : (F <= 128 ? std::min(2, sweep_vec_from_env()) : sweep_vec_from_env());
+        switch (v) {
             case 4: TGCN_CHECK(launch_sweep<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
             case 2: TGCN_CHECK(launch_sweep<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
             default: TGCN_CHECK(launch_sweep<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
@@ -612,7 +727,17 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
     }
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
-        if (VEC == 4 && F <= 128 && narrow_from_env()) {
+        // operand as one buffer below 4 GB (and rows addressable with 32-bit byte offsets): buffer-addressed form
+        const uint64_t x_extent = (static_cast<uint64_t>(blk.n_cols - 1) * static_cast<uint64_t>(ldx) + F) * 4u;
+        const bool buf_ok = split == INT32_MAX && x_extent <= 0xFFFF0000ull && narrow_buf_from_env();
+        if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
+            if (F <= 64)
+                k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
+                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc);
+            else
+                k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
+                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc);
+        } else if (VEC == 4 && F <= 128 && narrow_from_env()) {
             // narrow feature rows (the layer-2 width C): sub-group kernel
             if (F <= 64)
                 k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2,

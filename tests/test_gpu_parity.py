@@ -1010,11 +1010,12 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
 
 @pytest.mark.parametrize("n,n_hubs,weight,dup", [(20011, 40, 192, False), (9001, 33, 64, True), (30000, 600, 64, False)])
 def test_column_sweep_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_hubs, weight, dup):
-    """k_spmm_sweep: the long rows below the hot ones, accumulated in LDS while 8 x 32 workgroups walk the
-    column blocks.  Thresholds are lowered so that graphs of test size get the block (the defaults ask for
-    >= 256 such rows and >= 65 536 operand rows); checked against the oracle and against the same graph's
-    plan without it (TGCN_SWEEP=0) for every lane width of the sweep (1, 2, 4 floats per lane, several
-    column tiles), the transposed block of an asymmetric operator, split operands and strided results."""
+    """k_spmm_sweep (opt-in, TGCN_SWEEP=1): the long rows below the hot ones, accumulated in LDS while 8 x 32
+    workgroups walk the column blocks.  Thresholds are lowered so that graphs of test size get the block (the
+    defaults ask for >= 256 such rows and >= 65 536 operand rows); checked against the oracle and against the
+    same graph's plan without it for every lane width of the sweep (1, 2, 4 floats per lane, several column
+    tiles), heavy rows cut into pieces, the transposed block of an asymmetric operator, split operands and
+    strided results."""
     gen = torch.Generator().manual_seed(n)
     if n_hubs > 100:                                  # many mid-length rows: every wave slot gets several rows
         srcs, dsts = [], []
@@ -1028,6 +1029,7 @@ def test_column_sweep_block_matches_oracle_and_gather_path(cuda, monkeypatch, n,
     else:
         ei, w = _hub_graph(n, n_hubs, gen, dup)
     monkeypatch.setenv("TGCN_ITEM_WEIGHT", str(weight))
+    monkeypatch.setenv("TGCN_SWEEP", "1")             # the block is opt-in
     monkeypatch.setenv("TGCN_SWEEP_MIN_ROWS", "1")
     monkeypatch.setenv("TGCN_SWEEP_MIN_COLS", "1")
     monkeypatch.setenv("TGCN_SWEEP_SHARE", "0")
@@ -1035,12 +1037,12 @@ def test_column_sweep_block_matches_oracle_and_gather_path(cuda, monkeypatch, n,
     st = plan.stats()
     assert st["sweep_rows"] >= 512 and st["sweep_rows"] % 512 == 0 and st["sweep_nnz"] > 0
     if n_hubs > 100:
-        assert st["sweep_rows"] == 1024               # 600 rows -> two rows per wave slot (some slots hold one)
+        assert st["sweep_rows"] >= 1024               # 600 rows in pieces -> several local rows per wave slot
     assert plan.query(_lib.Q_SWEEP_ROWS_T) >= 512 and not plan.symmetric
     monkeypatch.setenv("TGCN_SWEEP", "0")
     plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
     assert plain.stats()["sweep_rows"] == 0
-    monkeypatch.delenv("TGCN_SWEEP")
+    monkeypatch.setenv("TGCN_SWEEP", "1")
     for F in (200, 64, 8, 132, 260, 520, 100, 7):
         x = torch.randn(n, F, generator=gen)
         b = torch.randn(F, generator=gen)
