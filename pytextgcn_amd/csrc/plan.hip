@@ -646,16 +646,59 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             }
             sweep_carry_rows = pb * kSweepLabels;
             std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.size > y.size; });
-            std::vector<int64_t> load(kSweepSlots, 0);
+            // Slots must carry equal work not only in total but along the way: every wave of a label walks
+            // the columns in the same order, and waves whose rows have their entries in different column
+            // REGIONS (a word row with mostly word neighbours against one with mostly documents) would be
+            // hundreds of column blocks apart most of the time.  The columns are therefore cut into kReg regions
+            // of equal swept mass (from the column-block cut positions of the long rows) and a piece goes to
+            // the slot whose fullest region stays lowest.
+            constexpr int kReg = 16;
+            std::vector<int> region_of(static_cast<size_t>(std::max(n_cb, 1)), 0);
+            const bool by_region = n_cb > 1;
+            if (by_region) {
+                std::vector<int64_t> mass(static_cast<size_t>(n_cb), 0);
+                for (size_t m = 0; m < take; ++m) {
+                    const int32_t *c = cuts.data() + static_cast<size_t>(cand[m]) * (n_cb + 1);
+                    for (int32_t j = 0; j < n_cb; ++j) mass[j] += c[j + 1] - c[j];
+                }
+                int64_t run = 0;
+                for (int32_t j = 0; j < n_cb; ++j) {
+                    region_of[j] = static_cast<int>(std::min<int64_t>(kReg - 1, run * kReg / std::max<int64_t>(total, 1)));
+                    run += mass[j];
+                }
+            }
+            std::vector<double> rvec(take * kReg, 0.0);               // entries of row m in region r
+            std::vector<double> target(kReg, 0.0);
+            for (size_t m = 0; m < take; ++m) {
+                if (by_region) {
+                    const int32_t *c = cuts.data() + static_cast<size_t>(cand[m]) * (n_cb + 1);
+                    for (int32_t j = 0; j < n_cb; ++j) rvec[m * kReg + region_of[j]] += c[j + 1] - c[j];
+                } else {
+                    rvec[m * kReg] = deg(cand[m]);
+                }
+                for (int r = 0; r < kReg; ++r) target[r] += rvec[m * kReg + r] / kSweepSlots;
+            }
+            for (int r = 0; r < kReg; ++r) target[r] = std::max(target[r], 1.0);
+            std::vector<double> load(static_cast<size_t>(kSweepSlots) * kReg, 0.0);
             std::vector<int32_t> count(kSweepSlots, 0), piece_li(static_cast<size_t>(n_local), 0);
             std::vector<int32_t> out_row(static_cast<size_t>(n_sweep), -1);   // local row -> carry row of its label 0
             for (const Piece &pc : pieces) {
+                const double inv_k = 1.0 / spieces[pc.m];
                 int best = -1;
-                for (int sl = 0; sl < kSweepSlots; ++sl)
-                    if (count[sl] < sweep_rw && (best < 0 || load[sl] < load[best])) best = sl;
+                double best_cost = 0.0;
+                for (int sl = 0; sl < kSweepSlots; ++sl) {
+                    if (count[sl] >= sweep_rw) continue;
+                    double cost = 0.0;
+                    for (int r = 0; r < kReg; ++r)
+                        cost = std::max(cost, (load[sl * kReg + r] + rvec[pc.m * kReg + r] * inv_k) / target[r]);
+                    if (best < 0 || cost < best_cost) {
+                        best = sl;
+                        best_cost = cost;
+                    }
+                }
                 const int32_t li = best * sweep_rw + count[best];
                 ++count[best];
-                load[best] += pc.size;
+                for (int r = 0; r < kReg; ++r) load[best * kReg + r] += rvec[pc.m * kReg + r] * inv_k;
                 piece_li[spbase[pc.m] + pc.q] = li;
                 out_row[li] = (spbase[pc.m] + pc.q) * kSweepLabels;
             }
