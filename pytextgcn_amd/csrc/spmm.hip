@@ -731,6 +731,8 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         const uint64_t x_extent = (static_cast<uint64_t>(blk.n_cols - 1) * static_cast<uint64_t>(ldx) + F) * 4u;
         const bool buf_ok = split == INT32_MAX && x_extent <= 0xFFFF0000ull && narrow_buf_from_env();
         if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
+            // U = 4 gathers in flight per sub-group: 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows
+            // hold ~10 entries and every started group of U is gathered in full
             if (F <= 64)
                 k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
                                                             static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc);

@@ -142,6 +142,21 @@ class GraphPlan:
                                               _stream_ptr(self.device)))
         return rowptr, col, val
 
+    def _workspace(self, transpose: int, F: int, device) -> Optional[Tensor]:
+        """Carry workspace of one SpMM, kept per (stream, direction, width): the layer widths alternate every
+        call, and two streams (or threads on their own streams) must never share one (include/tgcn.h).  The
+        buffer only ever serves launches on the stream it is keyed by, so reuse is ordered by that stream."""
+        key = (torch.cuda.current_stream(device).cuda_stream, transpose, F)
+        cache = self.__dict__.setdefault("_ws_cache", {})
+        ws = cache.get(key)
+        if ws is None:
+            n = self._lib.tgcn_spmm_workspace_bytes(self._h, transpose, F)
+            ws = torch.empty(n, dtype=torch.uint8, device=device) if n else False
+            if len(cache) >= 16:
+                cache.clear()
+            cache[key] = ws
+        return ws if ws is not False else None
+
     # -- compute ----------------------------------------------------------------------------
     def spmm(self, x: Tensor, bias: Optional[Tensor] = None, transpose: bool = False,
              out: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
@@ -177,8 +192,8 @@ class GraphPlan:
             out = torch.empty(n_out, F, dtype=torch.float32, device=x.device)
         elif out.shape != (n_out, F) or out.dtype != torch.float32 or out.stride(1) != 1:
             raise ValueError("`out` must be float32 [n_rows, F] with unit column stride")
-        ws_bytes = self._lib.tgcn_spmm_workspace_bytes(self._h, int(transpose), F)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        ws = self._workspace(int(transpose), F, x.device)
+        ws_bytes = ws.numel() if ws is not None else 0
         _lib.check(self._lib.tgcn_spmm_split(
             self._h, int(transpose), x.data_ptr(), x.stride(0),
             x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, split, F,
