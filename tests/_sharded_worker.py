@@ -64,7 +64,7 @@ def make_graph(kind):
         return g, torch.arange(30000) < g.n_vocab
     if kind == "wordoc_allhubs":
         return synth.word_doc_graph(400, 4000, seed=12, n_classes=5), None
-    if kind == "asym":
+    if kind in ("asym", "asym_keep_loops", "asym_raw"):
         g = synth.random_graph(300, 2500, seed=13, self_loops=7, duplicates=11)
         g.y = torch.randint(0, 5, (300,), generator=torch.Generator().manual_seed(1))
         g.train_mask = torch.rand(300, generator=torch.Generator().manual_seed(2)) < 0.5
@@ -80,6 +80,24 @@ def check(kind, device="cpu"):
     N = g.y.numel()
     if device != "cpu":
         return check_hip(kind, g, hubs, N, torch.device(device))
+    if kind in ("asym_keep_loops", "asym_raw"):
+        # GCNConv(add_self_loops=False): input loops stay ordinary edges, none are added;
+        # GCNConv(normalize=False): the raw weights, no loops (PyG adds them inside gcn_norm only)
+        norm = kind == "asym_keep_loops"
+        sg = sharded.ShardedGraph(g.edge_index, g.edge_attr, N, hubs=None, engine=OracleEngine(),
+                                  add_self_loops=False, normalize=norm)
+        assert not sg.symmetric
+        gen = torch.Generator().manual_seed(6)
+        x = torch.randn(N, 9, generator=gen)
+        if norm:
+            nei, nw = O.gcn_norm(g.edge_index, g.edge_attr, N, add_self_loops=False)
+        else:
+            nei, nw = g.edge_index, g.edge_attr
+        for transpose in (False, True):
+            ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N)
+            got = sg.gather_rows(sg.spmm(sg.scatter_rows(x), None, transpose=transpose))
+            assert rel_err(got, ref) < 1e-5, (kind, transpose, rel_err(got, ref))
+        return
     if kind == "wordoc":
         sg = sharded.ShardedGraph.from_data(g, engine=OracleEngine())          # hubs = words, from n_vocab
         assert torch.equal(sg.part.hub_mask, hubs)

@@ -82,6 +82,39 @@ def test_plan_matches_gcn_norm(cuda, seed, n, e, loops, dups, weighted, add_loop
     assert plan.symmetric is False or e == 0
 
 
+@pytest.mark.parametrize("add_loops,chunk", [(1, None), (1, "1024"), (2, "1500"), (0, "1024")])
+def test_gcn_norm_entry_point_matches_the_oracle(cuda, monkeypatch, add_loops, chunk):
+    """tgcn_gcn_norm (the normalisation half of the plan on its own, used by the 1-D partition): deg^-1/2 and
+    the loop weight per node against the oracle's add_remaining_self_loops + degree sum, with the edge list
+    walked in one chunk and in many (TGCN_NORM_CHUNK), loops of weight 1 / 2 (improved) / none, and the
+    non-contiguous edge_index view of the reference (text2graph.py:192)."""
+    from pytextgcn_amd.sharded import HipEngine
+    if chunk is not None:
+        monkeypatch.setenv("TGCN_NORM_CHUNK", chunk)
+    g = synth.random_graph(3000, 40000, seed=5, self_loops=25, duplicates=60)
+    ei, w = g.edge_index, g.edge_attr
+    if add_loops:
+        ei2, w2 = O.add_remaining_self_loops(ei, w, float(add_loops), 3000)
+        loop_ref = w2[-3000:]
+    else:
+        ei2, w2, loop_ref = ei, w, torch.zeros(3000)
+    deg = torch.zeros(3000, dtype=torch.float64).index_add_(0, ei2[1], w2.double())
+    dis_ref = deg.pow(-0.5)
+    dis_ref[torch.isinf(dis_ref)] = 0
+    ei_view = ei.t().contiguous().to(cuda).t()                   # [2, E] view with strides (1, 2)
+    dis, loop_w = HipEngine().gcn_norm(ei_view, w.to(cuda), 3000, add_loops)
+    assert torch.equal(loop_w.cpu(), loop_ref)
+    assert rel_err(dis, dis_ref.float()) < 1e-6
+    # isolated node: degree 0 -> inf -> 0 (masked_fill), with and without its loop
+    ei3 = torch.tensor([[0, 1], [1, 0]])
+    d3, l3 = HipEngine().gcn_norm(ei3.to(cuda), None, 3, add_loops)
+    want = {1: [2 ** -0.5, 2 ** -0.5, 1.0], 2: [3 ** -0.5, 3 ** -0.5, 2 ** -0.5], 0: [1.0, 1.0, 0.0]}[add_loops]
+    assert torch.allclose(d3.cpu(), torch.tensor(want), atol=1e-6)
+    assert l3.cpu().tolist() == [float(add_loops)] * 3
+    with pytest.raises(IndexError):
+        HipEngine().gcn_norm(torch.tensor([[0, 5], [1, 0]]).to(cuda), None, 3, 1)
+
+
 def test_symmetric_graph_is_detected_and_shares_one_copy(cuda):
     g = synth.word_doc_graph(2000, 24000, seed=2, device=cuda)
     plan = GraphPlan(g.edge_index, g.edge_attr, 2000)

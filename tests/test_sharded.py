@@ -64,6 +64,11 @@ def test_world3_asymmetric_graph_and_uneven_shards():
     run(3, ["asym", "wordoc"])
 
 
+def test_world2_without_added_loops_and_without_normalisation():
+    """GCNConv(add_self_loops=False) and GCNConv(normalize=False) through the chunked operator construction."""
+    run(2, ["asym_keep_loops", "asym_raw"])
+
+
 def test_world4_hub_partition():
     run(4, ["wordoc"])
 
