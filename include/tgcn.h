@@ -161,6 +161,23 @@ int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_
                     int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
                     void *workspace, size_t workspace_bytes, tgcn_stream stream);
 
+/* tgcn_spmm_adam -- tgcn_spmm whose result rows are never stored: row r of M(^T) @ G is the GRADIENT of row r of
+ * `param` and is spent at once on torch.optim.Adam's update of that row (the arithmetic of tgcn_adam_step, op for
+ * op; max_exp_avg_sq = NULL means amsgrad=False).  For TextGCN's one-hot features the first layer's weight
+ * gradient IS such a product, dW1 = M^T dH1 (the reference computes it at
+ * flat_amazon.py:105 and applies it at :106): fusing the two removes the N x h gradient and the optimizer's own pass
+ * over W1 and its state.  Same bits as tgcn_spmm followed by tgcn_adam_step.
+ *   G [n_cols, F] fp32 stride ldg;  param / exp_avg / exp_avg_sq / max_exp_avg_sq [n_rows, F] stride ldp
+ *   F %% 4 == 0, strides multiples of 4, 16-byte aligned buffers (no scalar fallback: TGCN_E_INVALID otherwise)
+ *   step  1-based step count AFTER increment; with scalars_dev != NULL the two step-dependent factors are read
+ *         from that device buffer instead ({lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)}, as tgcn_adam_step_capturable
+ *         leaves them in its `scalars_dev`), so that a captured HIP graph can be replayed per step.
+ * Workspace: tgcn_spmm_workspace_bytes(plan, transpose, F). */
+int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t ldg, int F, float *param,
+                   float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, int64_t ldp, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                   const float *scalars_dev, void *workspace, size_t workspace_bytes, tgcn_stream stream);
+
 /* tgcn_colsum -- replaces the autograd of `out += bias` (db = sum over rows of dOut).
  *   G [n_rows, F] fp32 stride ldg -> out [F]. */
 size_t tgcn_colsum_workspace_bytes(int64_t n_rows, int F);

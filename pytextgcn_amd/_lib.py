@@ -39,6 +39,9 @@ SIGNATURES = {
                           c_void_p, c_size_t, c_void_p]),
     "tgcn_spmm_split": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_spmm_adam": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
     "tgcn_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "tgcn_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),

@@ -19,6 +19,11 @@ from . import dense
 from .plan import GraphPlan, colsum, plan_for
 
 
+def _fused_optimizer_for(param):
+    from .optim import fused_optimizer_for      # late import: optim imports nothing from here, but keep it lazy
+    return fused_optimizer_for(param)
+
+
 def _pad_cols(t: Tensor, width: int) -> Tensor:
     if t.size(-1) == width:
         return t
@@ -37,6 +42,9 @@ class _Propagate(torch.autograd.Function):
         ctx.plan = plan
         ctx.F = F
         ctx.has_bias = bias is not None
+        # the operand IS a parameter whose optimizer asked for the update to happen in this backward
+        # (pytextgcn_amd.optim.Adam.fuse_into_backward): TextGCN's W1 under one-hot features
+        ctx.fused_param = xw if (isinstance(xw, nn.Parameter) and _fused_optimizer_for(xw) is not None) else None
         return out if F4 == F else out[:, :F]
 
     @staticmethod
@@ -46,9 +54,14 @@ class _Propagate(torch.autograd.Function):
         g = _pad_cols(grad_out, F4).contiguous()
         d_xw = d_bias = None
         if ctx.needs_input_grad[1]:
-            d_xw = plan.spmm(g, None, transpose=True)
-            if F4 != F:
-                d_xw = d_xw[:, :F]
+            p = getattr(ctx, "fused_param", None)
+            opt = _fused_optimizer_for(p) if p is not None else None
+            if opt is not None and F4 == F and opt._fused_update(p, plan, g):
+                d_xw = None                       # spent on the optimizer row by row, never stored
+            else:
+                d_xw = plan.spmm(g, None, transpose=True)
+                if F4 != F:
+                    d_xw = d_xw[:, :F]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             d_bias = colsum(g)[:F]
         return None, d_xw, d_bias
@@ -62,6 +75,7 @@ class _PropagateCached(torch.autograd.Function):
         ctx.plan = plan
         ctx.F = xw.size(1)
         ctx.has_bias = bias is not None
+        ctx.fused_param = xw if (isinstance(xw, nn.Parameter) and _fused_optimizer_for(xw) is not None) else None
         return value.detach()
 
     @staticmethod

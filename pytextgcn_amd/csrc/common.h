@@ -111,6 +111,30 @@ int colsum_blocks(int64_t n_rows);
 
 inline int64_t round_up4(int64_t v) { return (v + 3) & ~int64_t(3); }
 
+// One element of torch.optim.Adam's update (torch/optim/adam.py, _single_tensor_adam), shared by the
+// stand-alone optimizer pass (train.hip: k_adam) and the optimizer fused into the SpMM epilogue (spmm.hip):
+//   g += wd * p;  m.lerp_(g, 1 - b1);  v = b2 * v + (1 - b2) * g * g;  vmax = max(vmax, v)   [amsgrad]
+//   p -= step_size * m / (sqrt(vmax or v) * inv_bc2_sqrt + eps)
+// Floating-point contraction is switched OFF inside: both callers must produce the same bits for the same
+// inputs (tgcn_spmm_adam == tgcn_spmm + tgcn_adam_step), whatever the surrounding code lets the compiler fuse.
+__device__ __forceinline__ void adam_element(float &p, const float g, float &m, float &v, float &vmax,
+                                             const bool amsgrad, const float w1, const float b2, const float w2,
+                                             const float eps, const float wd, const float step_size,
+                                             const float inv_bc2_sqrt) {
+#pragma clang fp contract(off)
+    const float gr = g + wd * p;
+    const float diff = gr - m;
+    m = w1 < 0.5f ? m + w1 * diff : gr - diff * (1.f - w1);   // at::lerp: monotone in the weight
+    v = v * b2 + (w2 * gr) * gr;
+    float d = v;
+    if (amsgrad) {
+        vmax = fmaxf(vmax, v);
+        d = vmax;
+    }
+    const float denom = sqrtf(d) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
 }  // namespace tgcn
 
 struct tgcn_plan {

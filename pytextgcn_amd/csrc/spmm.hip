@@ -20,6 +20,7 @@
 //     order (LDS across the 4 waves), so the result is bitwise reproducible.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -91,17 +92,55 @@ __device__ __forceinline__ float readlane_f(int bits, int lane) {
 
 constexpr int kWavesPerBlock = 4;
 
+// Optimizer fused into the epilogue (tgcn_spmm_adam): the finished row is the GRADIENT of one parameter row
+// -- for one-hot features dW1 = M^T dH1 -- and instead of being written it is
+// consumed on the spot by torch.optim.Adam's update of that row (the arithmetic of k_adam in train.hip, op
+// for op), so that the N x h gradient is never stored and the optimizer's own pass over W1 disappears.
+struct AdamRow {
+    float *p, *m, *v, *vmax;     // parameter, exp_avg, exp_avg_sq, max_exp_avg_sq (nullptr: amsgrad off)
+    int64_t ld;                  // common row stride (elements)
+    float w1, b2, w2, eps, wd;   // 1 - beta1, beta2, 1 - beta2, eps, weight decay
+    float step_size, inv_bc2_sqrt;
+    const float *dev_scalars;    // {step_size, inv_bc2_sqrt} on the device (capturable form) or nullptr
+};
+
+struct AdamState4 {              // the optimizer state of one lane's four elements, in flight while the row is summed
+    float4 p, m, v, x;
+};
+
+__device__ __forceinline__ void adam_prefetch(const AdamRow &ad, int64_t off, AdamState4 &st) {
+    st.p = *reinterpret_cast<const float4 *>(ad.p + off);
+    st.m = Vec<4>::load_nt(ad.m + off);
+    st.v = Vec<4>::load_nt(ad.v + off);
+    st.x = ad.vmax != nullptr ? Vec<4>::load_nt(ad.vmax + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void adam_update(const AdamRow &ad, int64_t off, const float4 &g4, AdamState4 &st,
+                                            float step_size, float inv_bc2_sqrt) {
+    float *P = &st.p.x, *M = &st.m.x, *V = &st.v.x, *X = &st.x.x;
+    const float *G = &g4.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        adam_element(P[k], G[k], M[k], V[k], X[k], ad.vmax != nullptr, ad.w1, ad.b2, ad.w2, ad.eps, ad.wd, step_size,
+                     inv_bc2_sqrt);
+    *reinterpret_cast<float4 *>(ad.p + off) = st.p;
+    Vec<4>::store_nt(ad.m + off, st.m);
+    Vec<4>::store_nt(ad.v + off, st.v);
+    if (ad.vmax != nullptr) Vec<4>::store_nt(ad.vmax + off, st.x);
+}
+
 // One work item on one wavefront.  POLICY bits (cache hints, chosen by measurement): 1 = non-temporal
 // (col,val) stream, 2 = non-temporal result stores.  The gathered rows themselves always use plain
 // loads: a non-temporal hint on them destroys the L2 / Infinity-Cache re-use (7.5 ms instead of 4.4),
 // and even a per-entry "cold column" hint behind a branch cost more than it saved.
-template <int VEC, int U, int POLICY>
+template <int VEC, int U, int POLICY, bool ADAM = false>
 __device__ __forceinline__ void spmm_item(
     const WorkItem it, const int lane, const int col0, const int F,
     const int32_t *__restrict__ rowptr, const int2 *__restrict__ cv, const float *__restrict__ X,
     const int64_t ldx, const float *__restrict__ X2, const int64_t ldx2, const int split,
     const float *__restrict__ bias, float *__restrict__ Y, const int64_t ldy,
-    float *__restrict__ carry, const int64_t ldc) {
+    float *__restrict__ carry, const int64_t ldc, const AdamRow ad = AdamRow{}) {
+    static_assert(!ADAM || VEC == 4, "the fused optimizer epilogue is written for float4 lanes");
     using V = Vec<VEC>;
     using vec_t = typename V::type;
     const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;  // vectors in this column tile
@@ -141,9 +180,31 @@ __device__ __forceinline__ void spmm_item(
             return cv[idx];
         }
     };
+    // ADAM: the optimizer state of the row being summed is loaded when the row starts and is in flight under its
+    // gathers; the finished sum (+ bias) is the gradient of that row
+    AdamState4 ast;
+    float a_step = ad.step_size, a_ibc2 = ad.inv_bc2_sqrt;
+    if constexpr (ADAM) {
+        if (ad.dev_scalars != nullptr) {
+            a_step = ad.dev_scalars[0];
+            a_ibc2 = ad.dev_scalars[1];
+        }
+        if (!segment && r < it.row_end && active) adam_prefetch(ad, int64_t(r) * ad.ld + lc, ast);
+    }
+    auto finish_row = [&]() {
+        if constexpr (ADAM) {
+            if (active) {
+                const vec_t g = V::add(acc, bvec);
+                adam_update(ad, int64_t(r) * ad.ld + lc, g, ast, a_step, a_ibc2);
+                if (r + 1 < it.row_end) adam_prefetch(ad, int64_t(r + 1) * ad.ld + lc, ast);
+            }
+        } else {
+            store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
+        }
+    };
     auto flush_row = [&]() {
-        // row r is complete: write it, move to the next one
-        store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
+        // row r is complete: write it (or spend it on the optimizer), move to the next one
+        finish_row();
         acc = V::zero();
         ++r;
         if (r - rp_base == 64) {
@@ -189,7 +250,7 @@ __device__ __forceinline__ void spmm_item(
     } else {
         // last row with entries, then any trailing empty rows of the block
         while (r < it.row_end) {
-            store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
+            finish_row();
             acc = V::zero();
             ++r;
         }
@@ -209,6 +270,23 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     if (item_id >= n_items) return;
     spmm_item<VEC, U, POLICY>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, X2, ldx2,
                               split, bias, Y, ldy, carry, ldc);
+}
+
+// The same kernel with the optimizer in its epilogue.  U = 4: the 16 registers of optimizer state in flight take
+// the place of four gathered rows; 76 VGPRs = 6 waves per SIMD (forcing 64 spills) -- the launch moves twice the
+// HBM bytes of the plain one and is bound by them, not by the number of gathers in flight.
+template <int U>
+__global__ __launch_bounds__(256) void k_spmm_gather_adam(
+    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ X2, int64_t ldx2, int split, int F, const float *__restrict__ bias,
+    float *__restrict__ carry, int64_t ldc, const AdamRow ad) {
+    const int lane = threadIdx.x & 63;
+    const int item_id =
+        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item_id >= n_items) return;
+    spmm_item<4, U, 1, true>(items[item_id], lane, blockIdx.y * 256, F, rowptr, cv, X, ldx, X2, ldx2, split, bias,
+                             nullptr, 0, carry, ldc, ad);
 }
 
 // Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row): the wave splits into
@@ -578,11 +656,12 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
 
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
-template <int VEC>
+template <int VEC, bool ADAM = false>
 __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ fix,
                                                   const float *__restrict__ carry, int64_t ldc,
                                                   const float *__restrict__ bias,
-                                                  float *__restrict__ Y, int64_t ldy, int F) {
+                                                  float *__restrict__ Y, int64_t ldy, int F,
+                                                  const AdamRow ad = AdamRow{}) {
     using V = Vec<VEC>;
     using vec_t = typename V::type;
     __shared__ vec_t red[kWavesPerBlock][64];
@@ -610,7 +689,15 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
     if (wave == 0 && active) {
         vec_t t = V::add(V::add(red[0][lane], red[1][lane]), V::add(red[2][lane], red[3][lane]));
         if (bias != nullptr) t = V::add(t, *reinterpret_cast<const vec_t *>(bias + lc));
-        *reinterpret_cast<vec_t *>(Y + int64_t(fe.row) * ldy + lc) = t;
+        if constexpr (ADAM) {
+            AdamState4 st;
+            const int64_t off = int64_t(fe.row) * ad.ld + lc;
+            adam_prefetch(ad, off, st);
+            adam_update(ad, off, t, st, ad.dev_scalars ? ad.dev_scalars[0] : ad.step_size,
+                        ad.dev_scalars ? ad.dev_scalars[1] : ad.inv_bc2_sqrt);
+        } else {
+            *reinterpret_cast<vec_t *>(Y + int64_t(fe.row) * ldy + lc) = t;
+        }
     }
 }
 
@@ -683,9 +770,11 @@ int launch_sweep(const CsrBlock &b, const float *X, int64_t ldx, const float *X2
     return TGCN_OK;
 }
 
+// `ad` != nullptr (VEC == 4 only): the finished rows are spent on the optimizer instead of being stored in Y
 template <int VEC>
 int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
-               int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
+               int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream,
+               const AdamRow *ad = nullptr) {
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
     const int64_t ldc = round_up4(F);
     // With a dense hot block the float4 kernels run on the partition without the hot rows, next to
@@ -730,7 +819,14 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         // operand as one buffer below 4 GB (and rows addressable with 32-bit byte offsets): buffer-addressed form
         const uint64_t x_extent = (static_cast<uint64_t>(blk.n_cols - 1) * static_cast<uint64_t>(ldx) + F) * 4u;
         const bool buf_ok = split == INT32_MAX && x_extent <= 0xFFFF0000ull && narrow_buf_from_env();
-        if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
+        if (ad != nullptr) {
+            if constexpr (VEC == 4) {
+                // U = 2 / 4 / 8 gathered rows in flight measured the same (5.62-5.66 ms at c4): the launch is bound by
+                // the 37 GB it moves over the fabric, not by gather latency
+                k_spmm_gather_adam<4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split, F,
+                                                                bias, carry, ldc, *ad);
+            }
+        } else if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
             // U = 4 gathers in flight per sub-group: 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows
             // hold ~10 entries and every started group of U is gathered in full
             if (F <= 64)
@@ -765,7 +861,11 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
     }
     if (b.n_fix > 0) {
         dim3 grid(b.n_fix, tiles);
-        k_spmm_fix<VEC><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, Y, ldy, F);
+        if (ad != nullptr) {
+            if constexpr (VEC == 4) k_spmm_fix<4, true><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, nullptr, 0, F, *ad);
+        } else {
+            k_spmm_fix<VEC><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, Y, ldy, F);
+        }
         TGCN_HIP_CHECK(hipGetLastError());
     }
     return TGCN_OK;
@@ -788,9 +888,73 @@ int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
                 : launch_vec<1>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream);
 }
 
+// the SpMM whose rows feed the optimizer (tgcn_spmm_adam); float4 path only, checked by the caller
+int launch_spmm_adam(const CsrBlock &b, const float *X, int64_t ldx, int F, float *carry, hipStream_t stream,
+                     const AdamRow &ad) {
+    return launch_vec<4>(b, X, ldx, X, ldx, INT32_MAX, F, nullptr, nullptr, 0, carry, stream, &ad);
+}
+
 }  // namespace tgcn
 
 extern "C" {
+
+int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t ldg, int F, float *param,
+                   float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, int64_t ldp, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, int64_t step, const float *scalars_dev,
+                   void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+    using namespace tgcn;
+    if (!plan || !G || !param || !exp_avg || !exp_avg_sq) {
+        set_error("tgcn_spmm_adam: NULL plan / G / param / state");
+        return TGCN_E_INVALID;
+    }
+    if (F <= 0 || F % 4 != 0 || ldg < F || ldp < F || ldg % 4 != 0 || ldp % 4 != 0 || (step < 1 && !scalars_dev)) {
+        set_error("tgcn_spmm_adam: need F %% 4 == 0, ldg, ldp >= F and multiples of 4, step >= 1 (F=%d ldg=%lld ldp=%lld)",
+                  F, (long long)ldg, (long long)ldp);
+        return TGCN_E_INVALID;
+    }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(param) |
+                        reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
+                        reinterpret_cast<uintptr_t>(max_exp_avg_sq) | reinterpret_cast<uintptr_t>(workspace);
+    if (a % 16 != 0) {
+        set_error("tgcn_spmm_adam: buffers must be 16-byte aligned");
+        return TGCN_E_INVALID;
+    }
+    if (transpose && !plan->symmetric && !plan->has_transpose) {
+        set_error("tgcn_spmm_adam: transpose requested but the plan was built without it");
+        return TGCN_E_INVALID;
+    }
+    const size_t need = tgcn_spmm_workspace_bytes(plan, transpose, F);
+    if (need > 0 && (!workspace || workspace_bytes < need)) {
+        set_error("tgcn_spmm_adam: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        return TGCN_E_WORKSPACE;
+    }
+    const CsrBlock &b = (transpose && !plan->symmetric) ? plan->bwd : plan->fwd;
+    if (b.n_rows == 0) return TGCN_OK;
+    AdamRow ad;
+    ad.p = param;
+    ad.m = exp_avg;
+    ad.v = exp_avg_sq;
+    ad.vmax = max_exp_avg_sq;
+    ad.ld = ldp;
+    // every constant derived in double and rounded once, as tgcn_adam_step (and torch) do
+    const double st = static_cast<double>(step < 1 ? 1 : step);
+    const double bc1 = 1.0 - std::pow(beta1, st), bc2 = 1.0 - std::pow(beta2, st);
+    ad.w1 = static_cast<float>(1.0 - beta1);
+    ad.b2 = static_cast<float>(beta2);
+    ad.w2 = static_cast<float>(1.0 - beta2);
+    ad.eps = static_cast<float>(eps);
+    ad.wd = static_cast<float>(weight_decay);
+    ad.step_size = static_cast<float>(lr / bc1);
+    ad.inv_bc2_sqrt = static_cast<float>(1.0 / std::sqrt(bc2));
+    ad.dev_scalars = scalars_dev;
+    int cur = -1;
+    TGCN_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != plan->device) TGCN_HIP_CHECK(hipSetDevice(plan->device));
+    const int rc = launch_spmm_adam(b, G, ldg, F, need ? static_cast<float *>(workspace) : nullptr,
+                                    static_cast<hipStream_t>(stream), ad);
+    if (cur != plan->device) (void)hipSetDevice(cur);
+    return rc;
+}
 
 size_t tgcn_spmm_workspace_bytes(const tgcn_plan *plan, int transpose, int F) {
     if (!plan || F <= 0) return 0;

@@ -165,10 +165,6 @@ __global__ void k_ce_final(const float *__restrict__ partial, int n, float inv_c
     if (threadIdx.x == 0) *loss = red[0] * inv_count;
 }
 
-// at::lerp: the branch keeps the result monotone in the weight
-__device__ __forceinline__ float lerp_torch(float a, float b, float w) {
-    return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w);
-}
 
 // torch/optim/adam.py (_single_tensor_adam), op for op:
 //   g += wd * p;  m.lerp_(g, 1-b1);  v = b2*v + (1-b2)*g*g;  vmax = max(vmax, v)   [amsgrad]
@@ -231,35 +227,20 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
             float *P = &pp.x, *M = &mm.x, *V = &vv.x, *X = &xx.x;
             const float *G = &gg.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gr = G[k] + wd * P[k];
-                M[k] = lerp_torch(M[k], gr, w1);
-                V[k] = V[k] * b2 + w2 * gr * gr;
-                float d = V[k];
-                if (AMSGRAD) {
-                    X[k] = fmaxf(X[k], V[k]);
-                    d = X[k];
-                }
-                const float denom = sqrtf(d) * inv_bc2_sqrt + eps;
-                P[k] = P[k] - step_size * (M[k] / denom);
-            }
+            for (int k = 0; k < 4; ++k)
+                adam_element(P[k], G[k], M[k], V[k], X[k], AMSGRAD, w1, b2, w2, eps, wd, step_size, inv_bc2_sqrt);
             *reinterpret_cast<float4 *>(p + i) = pp;
             st4<NT>(m + i, mm);
             st4<NT>(v + i, vv);
             if (AMSGRAD) st4<NT>(vmax + i, xx);
         } else {
             for (int64_t j = i; j < n; ++j) {
-                const float gr = g[j] + wd * p[j];
-                const float mj = lerp_torch(m[j], gr, w1);
-                const float vj = v[j] * b2 + w2 * gr * gr;
-                float d = vj;
-                if (AMSGRAD) {
-                    d = fmaxf(vmax[j], vj);
-                    vmax[j] = d;
-                }
+                float pj = p[j], mj = m[j], vj = v[j], xj = AMSGRAD ? vmax[j] : 0.f;
+                adam_element(pj, g[j], mj, vj, xj, AMSGRAD, w1, b2, w2, eps, wd, step_size, inv_bc2_sqrt);
+                p[j] = pj;
                 m[j] = mj;
                 v[j] = vj;
-                p[j] = p[j] - step_size * (mj / (sqrtf(d) * inv_bc2_sqrt + eps));
+                if (AMSGRAD) vmax[j] = xj;
             }
         }
     }
@@ -356,7 +337,7 @@ static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp
         set_error("tgcn_adam_step: buffers must be 16-byte aligned");
         return TGCN_E_INVALID;
     }
-    if (n == 0) return TGCN_OK;
+    if (n == 0 && step_dev == nullptr) return TGCN_OK;
     // hyper-parameters are Python floats (doubles) in torch: derive every constant in double and
     // round once, as torch does when it hands `1 - beta2`, `lr / bias_correction1`, ... to its kernels
     const double bc1 = 1.0 - std::pow(beta1, static_cast<double>(step));
@@ -370,6 +351,7 @@ static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp
     if (step_dev != nullptr) {
         k_adam_scalars<<<1, 1, 0, s>>>(step_dev, lr, beta1, beta2, scalars_dev);
         TGCN_HIP_CHECK(hipGetLastError());
+        if (n == 0) return TGCN_OK;   // n = 0: only advance the device step (tgcn_spmm_adam applies the update)
     }
     // large tensors (W1: N x h) stream their state past the caches; TGCN_ADAM_NT=0/1 forces either form
     static const int nt_env = [] {

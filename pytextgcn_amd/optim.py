@@ -5,11 +5,28 @@ instead of torch's ~10 multi-tensor kernels.  W1 is N x h -- the largest tensor 
  -- so the optimizer is the largest cost of an epoch after the SpMMs."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch.optim import Optimizer
 
 from . import _lib
 from .plan import _stream_ptr
+
+
+# parameter -> the optimizer that updates it inside the backward pass (kept OUTSIDE the tensor's __dict__: the
+# reference pickles whole modules, flat_amazon.py:128, and a weak reference does not pickle)
+# keyed by id() and validated through a weak reference to the tensor (tensors compare element-wise, so they
+# cannot key a dict themselves; an id can be recycled once its tensor is gone)
+_FUSED: dict = {}
+
+
+def fused_optimizer_for(param):
+    """The live optimizer registered for `param` by Adam.fuse_into_backward, or None."""
+    hit = _FUSED.get(id(param))
+    if hit is None or hit[0]() is not param:
+        return None
+    return hit[1]()
 
 
 class Adam(Optimizer):
@@ -21,6 +38,59 @@ class Adam(Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       amsgrad=amsgrad, capturable=capturable))
+
+    def fuse_into_backward(self, param: torch.Tensor) -> None:
+        """Opt in to updating `param` INSIDE the backward pass: for a GCNConv layer on one-hot features
+        (TextGCN's first layer, text2graph.py:179) the weight gradient is the result of the transposed SpMM,
+        dW1 = M^T dH1, and `tgcn_spmm_adam` spends each finished row on this optimizer's update of that row
+        instead of storing it -- the N x h gradient and the optimizer's own pass over W1 disappear.  The
+        parameter then never receives a `.grad`; `step()` skips it and updates the others as usual.  Same bits
+        as backward + step.  Only for loops that call step() after every backward (flat_amazon.py:104-106):
+        gradient accumulation or retain_graph would apply the update once per backward."""
+        if not any(param is p for g in self.param_groups for p in g["params"]):
+            raise ValueError("fuse_into_backward: the tensor is not one of this optimizer's parameters")
+        key = id(param)
+        _FUSED[key] = (weakref.ref(param, lambda _, k=key: _FUSED.pop(k, None)), weakref.ref(self))
+
+    def _state_of(self, p, group):
+        st = self.state[p]
+        cap = group.get("capturable", False)
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.int64, device=p.device) if cap else 0
+            if cap:
+                st["scalars"] = torch.zeros(2, dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if group["amsgrad"]:
+                st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st, cap
+
+    @torch.no_grad()
+    def _fused_update(self, p, plan, g, transpose: bool = True) -> bool:
+        """Called from the backward of the propagate step whose operand is `p` (pytextgcn_amd.conv): apply this
+        step's update of p with grad = M(^T) @ g.  False = not applicable here (caller takes the plain path)."""
+        group = next((gr for gr in self.param_groups if any(p is q for q in gr["params"])), None)
+        if group is None or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.dim() != 2 \
+                or p.size(1) % 4 != 0 or p.size(1) <= 128 or g.stride(1) != 1 or g.stride(0) % 4 != 0:
+            return False                      # (widths <= 128 run the sub-group SpMM kernels, which sum in another order)
+        lib = _lib.load()
+        st, cap = self._state_of(p, group)
+        b1, b2 = group["betas"]
+        vmax = st.get("max_exp_avg_sq")
+        if cap:
+            # advance the device-side step and its two factors (n = 0: no elementwise pass), then the fused update
+            _lib.check(lib.tgcn_adam_step_capturable(
+                p.data_ptr(), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                vmax.data_ptr() if vmax is not None else None, 0, group["lr"], b1, b2, group["eps"],
+                group["weight_decay"], st["step"].data_ptr(), st["scalars"].data_ptr(), _stream_ptr(p.device)))
+            plan.spmm_adam(g, p, st["exp_avg"], st["exp_avg_sq"], vmax, group["lr"], b1, b2, group["eps"],
+                           group["weight_decay"], 0, scalars=st["scalars"], transpose=transpose)
+        else:
+            st["step"] += 1
+            plan.spmm_adam(g, p, st["exp_avg"], st["exp_avg_sq"], vmax, group["lr"], b1, b2, group["eps"],
+                           group["weight_decay"], st["step"], transpose=transpose)
+        torch.autograd.graph.increment_version(p)
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -39,16 +109,7 @@ class Adam(Optimizer):
                                        "parameters only (there is no CPU fallback)")
                 if p.grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients")
-                st = self.state[p]
-                cap = group.get("capturable", False)
-                if not st:
-                    st["step"] = torch.zeros((), dtype=torch.int64, device=p.device) if cap else 0
-                    if cap:
-                        st["scalars"] = torch.zeros(2, dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    if group["amsgrad"]:
-                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st, cap = self._state_of(p, group)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 vmax = st.get("max_exp_avg_sq")
                 if cap:

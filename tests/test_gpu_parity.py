@@ -542,6 +542,76 @@ def test_fused_training_loop_tracks_the_oracle(cuda):
 # ------------------------------------------------------------------------------------------------
 # dense X @ W on the fp32 matrix cores
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("amsgrad,wd,hidden", [(True, 0.0, 200), (False, 0.01, 132), (True, 0.0, 260)])
+def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, amsgrad, wd, hidden):
+    """optim.Adam.fuse_into_backward(W1): the rows of dW1 = M^T dH1 are spent on Adam inside tgcn_spmm_adam
+    (row blocks, long-row segments through k_spmm_fix, the dense hot block).  After several epochs of the
+    loop of flat_amazon.py:99-106 every parameter and every optimizer state must equal, BIT FOR BIT, those of
+    the same loop with the plain backward + step -- and W1 never holds a gradient."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.optim import Adam
+    N, C = 9000, 8
+    g = synth.word_doc_graph(N, 160000, seed=23, n_classes=C)
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    plan = GraphPlan(gd.edge_index, gd.edge_attr, N)
+    assert plan.stats()["long_rows"] > 0 and plan.stats()["hot_rows"] > 0      # every epilogue is exercised
+    torch.manual_seed(11)
+    base = pkg.GCN(N, C, n_hidden_gcn=hidden, dropout=0.0)
+    models, opts = [], []
+    for fused in (False, True):
+        m = pkg.GCN(N, C, n_hidden_gcn=hidden, dropout=0.0)
+        m.load_state_dict(base.state_dict())
+        m = m.to(cuda).float()
+        o = Adam(m.parameters(), lr=0.05, amsgrad=amsgrad, weight_decay=wd)
+        if fused:
+            o.fuse_into_backward(m.layers[0].weight)
+        models.append(m), opts.append(o)
+    for epoch in range(4):
+        for m, o, fused in zip(models, opts, (False, True)):
+            m.train()
+            loss = masked_cross_entropy(m(gd), gd.y, gd.train_mask)
+            o.zero_grad(set_to_none=True)
+            loss.backward()
+            if fused:
+                assert m.layers[0].weight.grad is None          # the gradient was never materialised
+            o.step()
+        for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+            assert torch.equal(pa, pb), epoch
+    sa, sb = opts[0].state[models[0].layers[0].weight], opts[1].state[models[1].layers[0].weight]
+    assert sa["step"] == sb["step"] == 4
+    for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+        assert torch.equal(sa[k], sb[k]), k
+    import pickle
+    pickle.dumps(models[1].layers[0].weight)                    # the registration lives outside the tensor
+
+
+def test_w1_update_fused_into_the_backward_under_graph_capture(cuda):
+    """The same with Adam(capturable=True) inside GraphedTrainStep: device-side step counter, one graph replay
+    per optimisation step; equal bit for bit to the eager capturable loop without the fusion."""
+    from pytextgcn_amd.optim import Adam
+    from pytextgcn_amd.train import GraphedTrainStep
+    N, C = 6000, 5
+    g = synth.word_doc_graph(N, 90000, seed=29, n_classes=C)
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    torch.manual_seed(3)
+    base = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+    res = []
+    for fused in (False, True):
+        m = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+        m.load_state_dict(base.state_dict())
+        m = m.to(cuda).float()
+        o = Adam(m.parameters(), lr=0.05, amsgrad=True, capturable=True)
+        if fused:
+            o.fuse_into_backward(m.layers[0].weight)
+        step = GraphedTrainStep(m, gd, o, gd.train_mask, warmup=2)
+        losses = [step().item() for _ in range(3)]
+        res.append((m, losses, o))
+    assert res[0][1] == res[1][1]
+    for pa, pb in zip(res[0][0].parameters(), res[1][0].parameters()):
+        assert torch.equal(pa, pb)
+    assert int(res[1][2].state[res[1][0].layers[0].weight]["step"].item()) == 5
+
+
 def test_mfma_gemm_identity_with_asymmetric_operand(cuda):
     """A = I with an ASYMMETRIC B catches a transposed fragment map (a symmetric B would not)."""
     from pytextgcn_amd import dense
