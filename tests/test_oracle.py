@@ -81,6 +81,30 @@ def test_csr_restatement_equals_gather_scatter(transpose):
     assert rel_err(csr_oracle.colsum(x), x.double().sum(0).float()) < 1e-6
 
 
+def test_restatement_equals_scipy_formulation_at_config_c2_size():
+    """A second, independent check of the restatement at benchmark scale (config c2: 100 k nodes, 2 M edges):
+    M = D^-1/2 (A + I) D^-1/2 assembled with scipy.sparse in float64 (no code shared with the oracle) against
+    gcn_norm + propagate in float32, forward and transposed, and against the C CSR restatement."""
+    import scipy.sparse as sp
+    N, E, F = 100_000, 2_000_000, 16
+    g = synth.word_doc_graph(N, E, seed=44)
+    ei, w = g.edge_index, g.edge_attr
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    A = sp.coo_matrix((w.double().numpy(), (dst, src)), shape=(N, N)).tocsr()      # M[target, source]
+    A = A + sp.identity(N, dtype=np.float64, format="csr")                          # no input loops in this graph
+    deg = np.asarray(A.sum(axis=1)).ravel()                                         # weighted in-degree at the target
+    dis = 1.0 / np.sqrt(deg)
+    M = sp.diags(dis) @ A @ sp.diags(dis)
+    x = torch.randn(N, F, generator=torch.Generator().manual_seed(7))
+    nei, nw = O.gcn_norm(ei, w, N)
+    for transpose in (False, True):
+        ref = torch.from_numpy((M.T if transpose else M) @ x.double().numpy()).float()
+        got = O.propagate(nei.flip(0) if transpose else nei, x, nw, N)
+        assert rel_err(got, ref) < 2e-6, transpose
+        rp, c, v = csr_oracle.normalized_csr(ei, w, N, transpose=transpose)
+        assert rel_err(csr_oracle.csr_spmm(rp, c, v, x), ref) < 2e-6, transpose
+
+
 def test_oracle_autograd_is_transposed_operator():
     g = synth.random_graph(50, 300, seed=4, self_loops=3, duplicates=4)
     x = torch.randn(50, 8, requires_grad=True)
