@@ -1,7 +1,7 @@
 #!/bin/bash
 # what the driver runs at round end: the GPU test-suite (with -x), smoke(), the default bench
 set -u
-R=gpurun_out/r02final
+R=gpurun_out/rehearsal
 mkdir -p $R
 timeout -k 10 1100 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $R/gpu_tests.log 2>&1
 rc=$?
