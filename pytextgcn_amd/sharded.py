@@ -114,6 +114,7 @@ def _entry_hash(r: Tensor, c: Tensor, vbits: Tensor, ks) -> int:
 class Partition:
     """Node -> (owner rank, slot) assignment; a pure function of (graph, world, hubs), so every
     rank computes the same one without communication."""
+    _CHUNK = 1 << 24      # edges per pass
 
     def __init__(self, edge_index: Tensor, num_nodes: int, world: int, hubs: Optional[Tensor]):
         dev = edge_index.device
@@ -127,13 +128,18 @@ class Partition:
             hub_mask = torch.zeros(N, dtype=torch.bool, device=dev)
             hub_mask[hubs.to(dev)] = True
         self.hub_mask = hub_mask
-        s, t = edge_index[0], edge_index[1]
         # work a node brings to its owner: a regular node all of its edges (as a column of A_r and as
         # a row of B_r); a hub only its hub-hub edges (its other entries are computed, as partial
-        # sums, by the ranks that own the regular endpoints)
-        deg_all = torch.bincount(s, minlength=N) + torch.bincount(t, minlength=N)
-        hh = hub_mask[s] & hub_mask[t]
-        deg_hh = torch.bincount(s[hh], minlength=N) + torch.bincount(t[hh], minlength=N)
+        # sums, by the ranks that own the regular endpoints).  The edge list is walked in chunks: nothing
+        # of size E is ever materialised next to it.
+        E = edge_index.size(1)
+        deg_all = torch.zeros(N, dtype=torch.int64, device=dev)
+        deg_hh = torch.zeros(N, dtype=torch.int64, device=dev)
+        for lo in range(0, E, self._CHUNK):
+            s, t = edge_index[0, lo:lo + self._CHUNK], edge_index[1, lo:lo + self._CHUNK]
+            deg_all += torch.bincount(s, minlength=N) + torch.bincount(t, minlength=N)
+            hh = hub_mask[s] & hub_mask[t]
+            deg_hh += torch.bincount(s[hh], minlength=N) + torch.bincount(t[hh], minlength=N)
         self.owner = torch.empty(N, dtype=torch.int64, device=dev)
         self.slot = torch.empty(N, dtype=torch.int64, device=dev)
         sizes = []
@@ -151,10 +157,14 @@ class Partition:
         self.hub_col = self.owner * self.hp + self.slot                # valid where hub_mask
         self.reg_col = world * self.hp + self.slot                     # valid where ~hub_mask
         # regular-regular edges must be rank-local
-        rr = (~hub_mask[s]) & (~hub_mask[t]) & (self.owner[s] != self.owner[t])
-        if bool(rr.any()):
+        bad = 0
+        if not bool(hub_mask.all()):
+            for lo in range(0, E, self._CHUNK):
+                s, t = edge_index[0, lo:lo + self._CHUNK], edge_index[1, lo:lo + self._CHUNK]
+                bad += int(((~hub_mask[s]) & (~hub_mask[t]) & (self.owner[s] != self.owner[t])).sum())
+        if bad:
             raise ValueError(
-                f"{int(rr.sum())} edges join regular (non-hub) nodes owned by different ranks; "
+                f"{bad} edges join regular (non-hub) nodes owned by different ranks; "
                 "enlarge `hubs` (hubs=None replicates every node: plain all-gather partition)")
 
     def owned(self, rank: int) -> Tensor:

@@ -542,8 +542,9 @@ def test_fused_training_loop_tracks_the_oracle(cuda):
 # ------------------------------------------------------------------------------------------------
 # dense X @ W on the fp32 matrix cores
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("amsgrad,wd,hidden", [(True, 0.0, 200), (False, 0.01, 132), (True, 0.0, 260)])
-def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, amsgrad, wd, hidden):
+@pytest.mark.parametrize("amsgrad,wd,hidden,asym", [(True, 0.0, 200, False), (False, 0.01, 132, False),
+                                                    (True, 0.0, 260, False), (True, 0.0, 200, True)])
+def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, amsgrad, wd, hidden, asym):
     """optim.Adam.fuse_into_backward(W1): the rows of dW1 = M^T dH1 are spent on Adam inside tgcn_spmm_adam
     (row blocks, long-row segments through k_spmm_fix, the dense hot block).  After several epochs of the
     loop of flat_amazon.py:99-106 every parameter and every optimizer state must equal, BIT FOR BIT, those of
@@ -551,9 +552,19 @@ def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, 
     from pytextgcn_amd.functional import masked_cross_entropy
     from pytextgcn_amd.optim import Adam
     N, C = 9000, 8
-    g = synth.word_doc_graph(N, 160000, seed=23, n_classes=C)
+    if asym:
+        # asymmetric weights, self loops, duplicates: the transposed block is a stored operator of its own
+        gen = torch.Generator().manual_seed(5)
+        ei, w = _hub_graph(N, 40, gen, dup=True)
+        ar = torch.arange(N)
+        g = pkg.Data(x=torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N), (N, N)).coalesce(),
+                     edge_index=ei, edge_attr=w, y=torch.randint(0, C, (N,), generator=gen),
+                     train_mask=torch.rand(N, generator=gen) < 0.6)
+    else:
+        g = synth.word_doc_graph(N, 160000, seed=23, n_classes=C)
     gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
     plan = GraphPlan(gd.edge_index, gd.edge_attr, N)
+    assert plan.symmetric != asym
     assert plan.stats()["long_rows"] > 0 and plan.stats()["hot_rows"] > 0      # every epilogue is exercised
     torch.manual_seed(11)
     base = pkg.GCN(N, C, n_hidden_gcn=hidden, dropout=0.0)
