@@ -243,10 +243,14 @@ def main(rank, world, port, kinds, errfile, backend="gloo", device="cpu"):
         if device != "cpu":
             device = device.format(rank=rank)              # "cuda:{rank}": one GPU per rank
             torch.cuda.set_device(torch.device(device))
+        # a bounded timeout: a mismatched collective must fail the test, not hang the box
+        import datetime
+        limit = datetime.timedelta(seconds=240)
         if backend == "nccl":
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(device))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(device),
+                                    timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
         for kind in kinds:
             check(kind, device)
         dist.barrier()
