@@ -581,6 +581,8 @@ def main():
                       else "one distributed SpMM on this rank: local SpMM launches + RCCL all-gather / reduce-scatter",
             # secondary denominator: this box's device-to-device copy rate (read + write)
             "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
+            # the measured HBM rate of the launch against what a plain copy reaches on THIS box
+            "frac_hbm_of_device_copy": None if hbm_bytes is None else hbm_bytes * per_s / copy_gbps,
             "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
             "algorithmic_bytes_per_launch": launch_bytes}
         out = {
