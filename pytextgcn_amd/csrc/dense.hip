@@ -29,8 +29,8 @@ constexpr int kMaxSmall = 256;  // k, n <= 256
 
 // Inverted dropout fused into the GEMMs around it (the dropout between the GCN layers,
 // textgcn/lib/models.py:23): element (row, col) of the [N x ld] activation is kept with probability
-// 1 - p and scaled by 1 / (1 - p).  The keep decision is a stateless hash of (seed, row * ld + col)
-// (murmur3 mixing steps), so the forward GEMM (mask on its A operand), the weight-gradient GEMM (mask on
+// 1 - p and scaled by 1 / (1 - p).  The keep decision is a stateless hash of (seed, row, col)
+// (murmur3-style mixing steps), so the forward GEMM (mask on its A operand), the weight-gradient GEMM (mask on
 // its A operand) and the input-gradient GEMM (mask on its result) regenerate the SAME mask from the
 // 8-byte seed instead of storing N x ld bytes.  The seed is read from device memory (graph capture).
 struct Drop {
@@ -40,20 +40,37 @@ struct Drop {
     int ld;                // logical width of the masked matrix
 };
 
-__device__ __forceinline__ float drop_apply(float v, uint32_t s_lo, uint32_t s_hi, int64_t row, int col,
-                                            const Drop &d) {
-    const uint64_t idx = uint64_t(row) * uint32_t(d.ld) + uint32_t(col);
-    uint32_t h = uint32_t(idx) ^ s_lo;
+// The hash is split so that the expensive part is paid once per ROW and lane, not once per element: a row key
+// (murmur3 mixing of the 64-bit row index with the seed) and, per element, key + col * golden-ratio constant
+// through a two-multiply finaliser.  (The first version hashed row * ld + col per element: 4 quarter-rate
+// 32-bit multiplies and a 64-bit multiply-add each; profiles/r02_pmc_gemm_c4.md: 4x the vector-ALU instructions
+// of the plain kernels.)  All three GEMMs call the same two functions, so they regenerate the same mask.
+__device__ __forceinline__ uint32_t drop_row_key(uint32_t s_lo, uint32_t s_hi, int64_t row) {
+    uint32_t h = uint32_t(row) ^ s_lo;
     h *= 0xcc9e2d51u;
     h = (h << 15) | (h >> 17);
     h *= 0x1b873593u;
-    h ^= uint32_t(idx >> 32) + s_hi;
+    h ^= uint32_t(uint64_t(row) >> 32) + s_hi;
     h ^= h >> 16;
     h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t drop_col_term(int col) { return uint32_t(col) * 0x9E3779B1u; }
+
+__device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t col_term, const Drop &d) {
+    uint32_t h = row_key + col_term;
+    h ^= h >> 15;
+    h *= 0x2c1b3c6du;
+    h ^= h >> 12;
+    h *= 0x297a2d39u;
+    h ^= h >> 15;
     return h >= d.thresh ? v * d.scale : 0.f;
+}
+
+__device__ __forceinline__ float drop_apply(float v, uint32_t s_lo, uint32_t s_hi, int64_t row, int col,
+                                            const Drop &d) {
+    return drop_elem(v, drop_row_key(s_lo, s_hi, row), drop_col_term(col), d);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -90,6 +107,8 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
     const int nq = kpad / 8;
     for (int64_t blk = int64_t(blockIdx.x) * 4 + wave; blk < n_blocks; blk += int64_t(gridDim.x) * 4) {
         const int64_t row = blk * 32 + r;
+        uint32_t a_key = 0;                    // dropout on the A operand: one row per lane and block
+        if constexpr (DROP && !TRANS_B) a_key = drop_row_key(s_lo, s_hi, row);
         // rows past the end shadow the last row: loads stay in bounds, their results are not stored
         const float *arow = A + std::min(row, N - 1) * lda + 4 * half;
         f32x16 acc[NT];
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
                 if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
-                        av[s4] = drop_apply(av[s4], s_lo, s_hi, row, 8 * q + 4 * half + s4, drop);
+                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(8 * q + 4 * half + s4), drop);
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
             if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
-                    av[s4] = drop_apply(av[s4], s_lo, s_hi, row, 8 * q + 4 * half + s4, drop);
+                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(8 * q + 4 * half + s4), drop);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
@@ -202,15 +221,22 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
         }
         }
         // C[(i&3) + 8*(i>>2) + 4*half][32 t + r]
+        uint32_t c_key[16];                    // dropout on the result: the lane's 16 rows, shared by all tiles
+        if constexpr (DROP && TRANS_B) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = 32 * t + r;
             if (col < n) {
+                const uint32_t cterm = drop_col_term(col);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
                     float out = acc[t][i];
-                    if constexpr (DROP && TRANS_B) out = drop_apply(out, s_lo, s_hi, orow, col, drop);
+                    if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
                     if (orow < N) C[orow * ldc + col] = out;
                 }
             }
@@ -284,8 +310,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         for (int u = 0; u < UR; ++u) {
             float x0 = a0[buf][u], x1 = a1[buf][u];
             if constexpr (DROP) {
-                x0 = drop_apply(x0, s_lo, s_hi, stage_row[buf] + 2 * u, ca0, drop);
-                x1 = drop_apply(x1, s_lo, s_hi, stage_row[buf] + 2 * u, ca1, drop);
+                const uint32_t key = drop_row_key(s_lo, s_hi, stage_row[buf] + 2 * u);
+                x0 = drop_elem(x0, key, drop_col_term(ca0), drop);
+                x1 = drop_elem(x1, key, drop_col_term(ca1), drop);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -310,8 +337,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         const float s = ok ? 1.f : 0.f;
         float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
         if constexpr (DROP) {
-            x0 = drop_apply(x0, s_lo, s_hi, r_begin + r + half - back, ca0, drop);
-            x1 = drop_apply(x1, s_lo, s_hi, r_begin + r + half - back, ca1, drop);
+            const uint32_t key = drop_row_key(s_lo, s_hi, r_begin + r + half - back);
+            x0 = drop_elem(x0, key, drop_col_term(ca0), drop);
+            x1 = drop_elem(x1, key, drop_col_term(ca1), drop);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
