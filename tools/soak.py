@@ -21,13 +21,15 @@ dev = torch.device("cuda:0")
 g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C)
 
 
-def train(reuse, collapse):
+def train(reuse, collapse, fuse_w1=False):
     pkg.enable_fused_dropout(True)
     pkg.enable_activation_reuse(reuse)
     pkg.enable_linear_collapse(collapse)
     torch.manual_seed(123)
     model = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.5).to(dev)
     opt = pkg.optim.Adam(model.parameters(), lr=0.01, amsgrad=True)
+    if fuse_w1:
+        opt.fuse_into_backward(model.layers[0].weight)       # W1's update inside the backward SpMM
     losses = []
     for _ in range(epochs):
         model.train()
@@ -59,4 +61,10 @@ for reuse, collapse in ((False, False), (True, False), (False, True)):
         # activation reuse is bitwise neutral: same trajectory as the plain run
         assert l1 == base[0] and all(torch.equal(a, b) for a, b in zip(w1, base[1])), "reuse changed the numbers"
         print("  activation reuse: trajectory identical to the plain run", flush=True)
+# the W1 update fused into the backward SpMM: repeatable, and the very trajectory of the plain loop
+l1, w1 = train(False, False, fuse_w1=True)
+l2, w2 = train(False, False, fuse_w1=True)
+assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(w1, w2)), "fused W1 update is not repeatable"
+assert l1 == base[0] and all(torch.equal(a, b) for a, b in zip(w1, base[1])), "fused W1 update changed the numbers"
+print(f"{cfg} W1 update in the backward SpMM: {epochs} epochs x 2, trajectory identical to the plain run", flush=True)
 print("soak ok")
