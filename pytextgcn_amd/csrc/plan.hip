@@ -403,7 +403,7 @@ Knobs knobs_from_env() {
     };
     Knobs k;
     k.col_block = geti("TGCN_COL_BLOCK", 8192);
-    k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 64));
+    k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 32));
     k.order = geti("TGCN_ITEM_ORDER", 3);
     k.hot_rows = geti("TGCN_HOT_ROWS", 1);
     const char *hr = std::getenv("TGCN_HOT_RATIO");
@@ -421,7 +421,8 @@ Knobs knobs_from_env() {
 int item_weight_from_env() {
     const char *s = std::getenv("TGCN_ITEM_WEIGHT");
     int v = s ? std::atoi(s) : 0;
-    if (v < 64 || v > (1 << 20)) v = 512;
+    if (v < 64 || v > (1 << 20)) v = 384;   // round-2 re-sweep (profiles/r02r_resweep_items.log): 384 / 32 is 3 % faster at
+                                            // F = 200 and 2 % slower at F = 64 than round 1's 512 / 64
     return v;
 }
 

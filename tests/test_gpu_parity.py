@@ -154,7 +154,7 @@ def test_spmm_strided_operands_and_noncontiguous_edge_index(cuda):
 
 @pytest.mark.parametrize("F", [200, 64, 7])
 def test_long_rows_are_split_and_reduced(cuda, F):
-    # a hub of degree 5000 >> item weight (512) plus one of exactly 512/513, among short rows
+    # a hub of degree 5000 >> item weight (384) plus rows of 513 / 512 entries (long too), among short rows
     n = 6000
     hub = torch.arange(1, 5001)
     src = torch.cat([hub, torch.zeros(5000, dtype=torch.long), torch.arange(1000, 1513),
@@ -1095,7 +1095,7 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
     assert not plan.symmetric
     for transpose, sel in ((False, _lib.Q_HOT_ROWS), (True, _lib.Q_HOT_ROWS_T)):
         rp = plan.export_csr(transpose)[0].long()
-        n_long = int(((rp[1:] - rp[:-1]) > 512).sum())           # rows longer than the item weight
+        n_long = int(((rp[1:] - rp[:-1]) > 384).sum())           # rows longer than the (default) item weight
         assert n_long >= min(n_hubs, 7) and plan.query(sel) == min(32, n_long)
     monkeypatch.setenv("TGCN_HOT_ROWS", "0")
     plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
