@@ -1,0 +1,28 @@
+#!/bin/bash
+# Evidence of a round (run on the GPU box; results land under gpurun_out/<tag>): rocprofv3 kernel stats and PMC
+# traffic of the bench command, the kernel table of an epoch, counters of the narrow kernel, the L2-resident
+# ceilings, HBM activity, and the bench record itself.   usage: tools/collect_evidence.sh <tag>
+set -u
+R=gpurun_out/${1:-evidence}
+mkdir -p $R
+root="$PWD"
+export TMPDIR=/tmp
+BENCH="$root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity"
+echo "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity" > $R/command.txt
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$R/stats -- python3 $BENCH > $root/$R/stats.log 2>&1 || { tail -5 $root/$R/stats.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/$R/fetch -- python3 $BENCH > $root/$R/fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/$R/write -- python3 $BENCH > $root/$R/write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$R/epoch -- python3 $root/tools/profile_epoch.py > $root/$R/epoch.log 2>&1 || exit 1
+cd $root
+timeout -k 10 600 tools/prof_pmc.sh "$root/$R/pmc_f64" "$root/tools/sweep_spmm.py" one c4 64 > /dev/null || exit 1
+python tools/summarize_pmc.py $R/pmc_f64 > $R/pmc_f64.md
+timeout -k 10 300 python tools/ceiling_spmm.py 200 > $R/ceiling_200.log 2>&1 || exit 1
+timeout -k 10 300 python tools/ceiling_spmm.py 64 > $R/ceiling_64.log 2>&1 || exit 1
+grep case $R/ceiling_200.log $R/ceiling_64.log
+timeout -k 10 300 python tools/hbm_activity.py --out $R/hbm_activity.json > $R/hbm_activity.log 2>&1 || exit 1
+tail -3 $R/hbm_activity.log | cut -c1-200
+timeout -k 10 600 python bench.py > $R/bench_c4_n1.json 2> $R/bench.err || exit 1
+cut -c1-300 $R/bench_c4_n1.json
+find $R -name "*_agent_info.csv" -delete
+du -sh $R
