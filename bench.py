@@ -526,7 +526,7 @@ def main():
     # the step contains collectives every rank must enter)
     hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
 
-    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = None
+    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
@@ -539,6 +539,7 @@ def main():
         epoch_ms_reuse = epoch_time_ms(g, F, C, fused=True, reuse=True)
         epoch_ms_collapse = epoch_time_ms(g, F, C, fused=True, collapse=True)
         epoch_ms_w1 = epoch_time_ms(g, F, C, fused=True, fuse_w1=True)
+        epoch_ms_w1_reuse = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True)    # both switches are bitwise neutral
 
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
@@ -612,6 +613,7 @@ def main():
             # the fused loop with W1's Adam update applied inside the backward SpMM (optim.Adam.fuse_into_backward):
             # every step of the epoch is still executed, bit for bit the same weights
             "epoch_ms_fused_w1_update_in_backward": epoch_ms_w1,
+            "epoch_ms_fused_w1_update_in_backward_with_activation_reuse": epoch_ms_w1_reuse,
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
         }

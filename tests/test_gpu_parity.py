@@ -596,6 +596,47 @@ def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, 
     pickle.dumps(models[1].layers[0].weight)                    # the registration lives outside the tensor
 
 
+def test_w1_update_in_the_backward_with_activation_reuse_keeps_the_trajectory(cuda):
+    """Both bitwise-neutral switches at once on the loop of flat_amazon.py:99-117 (train step, then an eval
+    forward on the new weights): the eval forward's M W1 + b1 is handed to the next training forward, and must
+    be dropped when the backward SpMM has moved W1 (the update goes through raw pointers; the version counter
+    of the parameter is what invalidates the cache)."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.optim import Adam
+    N, C = 7000, 6
+    g = synth.word_doc_graph(N, 110000, seed=31, n_classes=C)
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    torch.manual_seed(17)
+    base = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+    runs = []
+    try:
+        for switches in (False, True):
+            pkg.enable_activation_reuse(switches)
+            m = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+            m.load_state_dict(base.state_dict())
+            m = m.to(cuda).float()
+            o = Adam(m.parameters(), lr=0.05, amsgrad=True)
+            if switches:
+                o.fuse_into_backward(m.layers[0].weight)
+            trace = []
+            for _ in range(4):
+                m.train()
+                loss = masked_cross_entropy(m(gd), gd.y, gd.train_mask)
+                o.zero_grad(set_to_none=True)
+                loss.backward()
+                o.step()
+                m.eval()
+                with torch.no_grad():
+                    val = masked_cross_entropy(m(gd), gd.y, ~gd.train_mask)
+                trace.append((loss.item(), val.item()))
+            runs.append((trace, [p.detach().clone() for p in m.parameters()]))
+    finally:
+        pkg.enable_activation_reuse(False)
+    assert runs[0][0] == runs[1][0]
+    for pa, pb in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(pa, pb)
+
+
 def test_w1_update_fused_into_the_backward_under_graph_capture(cuda):
     """The same with Adam(capturable=True) inside GraphedTrainStep: device-side step counter, one graph replay
     per optimisation step; equal bit for bit to the eager capturable loop without the fusion."""

@@ -67,4 +67,8 @@ l2, w2 = train(False, False, fuse_w1=True)
 assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(w1, w2)), "fused W1 update is not repeatable"
 assert l1 == base[0] and all(torch.equal(a, b) for a, b in zip(w1, base[1])), "fused W1 update changed the numbers"
 print(f"{cfg} W1 update in the backward SpMM: {epochs} epochs x 2, trajectory identical to the plain run", flush=True)
+# both bitwise-neutral switches together (the cached M W1 + b1 must be dropped when the backward SpMM moves W1)
+l3, w3 = train(True, False, fuse_w1=True)
+assert l3 == base[0] and all(torch.equal(a, b) for a, b in zip(w3, base[1])), "reuse + fused W1 update changed the numbers"
+print(f"{cfg} activation reuse + W1 update in the backward SpMM: trajectory identical to the plain run", flush=True)
 print("soak ok")
