@@ -207,7 +207,7 @@ def hbm_activity(step_fn, dev, seconds=1.5):
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
-def epoch_time_ms(g, F, n_classes, fused, reps=3, reuse=False, collapse=False, fuse_w1=False):
+def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, fuse_w1=False):
     """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
     bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
     fused=False: the reference's loop body with its own operators (torch CrossEntropyLoss on
