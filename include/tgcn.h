@@ -208,6 +208,21 @@ int tgcn_masked_ce_pred(const float *logits, int64_t ld, int64_t n_rows, int n_c
                         float *dlogits, int64_t ldd, int64_t *pred, void *workspace,
                         size_t workspace_bytes, tgcn_stream stream);
 
+/* tgcn_masked_ce_grad -- tgcn_masked_ce_pred that also returns dbias[c] = sum_r dlogits[r, c]: the gradient of
+ * the bias of the layer that produced the logits (the autograd of `out += bias` in the last GCNConv, triggered
+ * at flat_amazon.py:105), summed from the registers that hold each gradient row instead of by a second pass
+ * over dlogits (tgcn_colsum).  Fixed summation order, no atomics.  dlogits and dbias [n_classes] are required;
+ * pred may be NULL. */
+size_t tgcn_masked_ce_grad_workspace_bytes(int64_t n_rows, int n_classes);
+int tgcn_masked_ce_grad(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                        float *dlogits, int64_t ldd, float *dbias, int64_t *pred, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream);
+/* tgcn_scale_by_device_scalar -- x[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1
+ * (multiplying by 1.0f is the identity): the chain rule through the loss node, whose incoming gradient is a
+ * device scalar the host cannot read without a synchronisation (`loss.backward()` seeds it with 1). */
+int tgcn_scale_by_device_scalar(float *x, int64_t n, const float *scale_dev, tgcn_stream stream);
+
 /* tgcn_adam_step -- one `torch.optim.Adam(..., amsgrad=...)` update of a flat fp32 tensor
  * (flat_amazon.py:89,106), torch's single-tensor formula op for op, fused into one pass.
  * max_exp_avg_sq = NULL means amsgrad=False.  `step` is the 1-based step count AFTER increment. */
@@ -248,6 +263,15 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
 int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                          int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
                          size_t workspace_bytes, tgcn_stream stream);
+/* tgcn_gemm_nt_colsum -- tgcn_gemm_nt (seed == NULL) or tgcn_gemm_nt_dropout (seed != NULL) that also returns
+ * colsum[j] = sum_r C[r, j], summed from the accumulator tiles as they are stored: with C = dH1 (the gradient of
+ * the first layer's output) this is that layer's bias gradient (the autograd of `out += bias`, triggered at
+ * flat_amazon.py:105), which otherwise costs a second pass over the N x h matrix (tgcn_colsum).  Fixed summation
+ * order, no atomics. */
+size_t tgcn_gemm_nt_colsum_workspace_bytes(int n);
+int tgcn_gemm_nt_colsum(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                        int64_t N, int k, int n, double p, const uint64_t *seed, float *colsum, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Word-word PMI edges (graph construction).  Replaces the reference's Cython

@@ -50,6 +50,10 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "tgcn_masked_ce_pred": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tgcn_masked_ce_grad_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "tgcn_masked_ce_grad": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tgcn_scale_by_device_scalar": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "tgcn_gemm_nn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p]),
     "tgcn_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
@@ -63,6 +67,9 @@ SIGNATURES = {
                                      c_double, c_void_p, c_void_p]),
     "tgcn_gemm_tn_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                      c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tgcn_gemm_nt_colsum_workspace_bytes": (c_size_t, [c_int]),
+    "tgcn_gemm_nt_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                    c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_wwedges_create": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p,
                                     POINTER(c_void_p)]),
     "tgcn_wwedges_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),

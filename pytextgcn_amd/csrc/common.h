@@ -108,6 +108,7 @@ int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
 int launch_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out, float *partial,
                   int n_blocks, hipStream_t stream);
 int colsum_blocks(int64_t n_rows);
+int launch_colsum_final(const float *partial, int n_partial, int F, float *out, hipStream_t stream);
 
 inline int64_t round_up4(int64_t v) { return (v + 3) & ~int64_t(3); }
 

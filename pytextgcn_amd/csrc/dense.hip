@@ -27,6 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxSmall = 256;  // k, n <= 256
 
+// Two workgroups per CU (a 256-register budget per lane) for the nt kernels with a masked result and / or column
+// sums: hipcc then keeps the accumulator tiles in the same register file as everything else instead of splitting
+// them off into AGPRs (186 + 112 registers = one wave per SIMD otherwise).  Measured at the c4 shapes
+// (tools/ab_dense.py, interleaved): nt + mask 0.88 -> 0.85 ms, nt + column sums 0.77 -> 0.72, nt + mask + column
+// sums 0.89 -> 0.81; the plain nt product is faster with the split (0.755 against 0.82 ms) and keeps it, the nn
+// product does not care (0.55 ms either way).
+#ifndef TGCN_TALL_MIN_BLOCKS
+#define TGCN_TALL_MIN_BLOCKS 2
+#endif
+
 // Inverted dropout fused into the GEMMs around it (the dropout between the GCN layers,
 // textgcn/lib/models.py:23): element (row, col) of the [N x ld] activation is kept with probability
 // 1 - p and scaled by 1 / (1 - p).  The keep decision is a stateless hash of (seed, row, col)
@@ -79,12 +89,18 @@ __device__ __forceinline__ float drop_apply(float v, uint32_t s_lo, uint32_t s_h
 // operand is read from memory: B[k][n] (nn) or B[n][k] (nt).
 // ---------------------------------------------------------------------------------------------
 // DROP: nn (TRANS_B = false) masks the A operand, nt (TRANS_B = true) masks the result.
-template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP>
-__global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
+// COLSUM: the workgroup also leaves the column sums of the rows of C it wrote (after the mask) in
+// colpart[blockIdx.x][0..n) -- for the nt product that is the bias gradient of the layer whose output the
+// product differentiates (db1 = column sums of dH1), taken from the accumulators instead of a second pass over C.
+template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP, bool COLSUM = false>
+__global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGCN_TALL_MIN_BLOCKS : 1) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
-                                                   int k, int n, const Drop drop) {
-    extern __shared__ float lds[];  // [kpad][npad]
+                                                   int k, int n, const Drop drop, float *__restrict__ colpart) {
+    extern __shared__ float lds[];  // [kpad][npad] (+ [4][npad] with COLSUM)
+    float csum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) csum[t] = 0.f;
     uint32_t s_lo = 0, s_hi = 0;
     if constexpr (DROP) {
         const uint64_t sd = *drop.seed;
@@ -237,10 +253,27 @@ __global__ __launch_bounds__(256) void k_gemm_tall(const float *__restrict__ A, 
                     const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
                     float out = acc[t][i];
                     if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
-                    if (orow < N) C[orow * ldc + col] = out;
+                    if (orow < N) {
+                        C[orow * ldc + col] = out;
+                        if constexpr (COLSUM) csum[t] += out;
+                    }
                 }
             }
+            // one tile at a time: the fence keeps hipcc from reading all NT accumulator tiles out at once
+            if constexpr (TRANS_B && (DROP || COLSUM)) __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (COLSUM) {
+        // a lane's rows in block order, then the two halves of the wave, then the four waves
+        float *cl = lds + ((k + 7) & ~7) * npad;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float v = csum[t] + __shfl_xor(csum[t], 32, 64);
+            if (half == 0) cl[wave * npad + 32 * t + r] = v;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x)
+            colpart[int64_t(blockIdx.x) * n + j] = (cl[j] + cl[npad + j]) + (cl[2 * npad + j] + cl[3 * npad + j]);
     }
 }
 
@@ -401,12 +434,16 @@ int tn_blocks(int64_t N) {
     return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(nb, 512)));
 }
 
-template <bool TRANS_B, bool DROP>
+constexpr int kTallMaxGrid = 256 * 4 * 2;   // upper bound of the persistent grid (CUs x resident workgroups), sizes colpart
+
+template <bool TRANS_B, bool DROP, bool COLSUM = false>
 int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                int64_t N, int k, int n, const Drop drop, hipStream_t s) {
+                int64_t N, int k, int n, const Drop drop, hipStream_t s, float *colpart = nullptr,
+                float *colsum = nullptr) {
     const int nt = (n + 31) / 32;
     const int kpad = (k + 7) & ~7;
-    const size_t lds_bytes = sizeof(float) * static_cast<size_t>(kpad) * (32 * nt);
+    const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(kpad) * (32 * nt) + (COLSUM ? 4 * 32 * nt : 0));
+    int grid_used = 0;
     if (lds_bytes > 160 * 1024) {
         set_error("tgcn_gemm: the small operand (%d x %d) does not fit the 160 KB LDS", k, n);
         return TGCN_E_INVALID;
@@ -423,15 +460,17 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
     }
 #define TGCN_TALL_K(NT, K8, NQ_)                                                                     \
     do {                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP>);      \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM>); \
         TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                            static_cast<int>(lds_bytes)));                         \
         int per_cu = 1;                                                                           \
         TGCN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes)); \
         per_cu = std::max(1, std::min(per_cu, 4));                                                \
-        const int grid = static_cast<int>(                                                        \
-            std::max<int64_t>(1, std::min<int64_t>((n_blocks + 3) / 4, int64_t(n_cu) * per_cu))); \
-        k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, drop); \
+        const int grid = static_cast<int>(std::max<int64_t>(                                      \
+            1, std::min<int64_t>({(n_blocks + 3) / 4, int64_t(n_cu) * per_cu, int64_t(kTallMaxGrid)}))); \
+        grid_used = grid;                                                                         \
+        k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
+                                                                                     drop, colpart); \
     } while (0)
 #define TGCN_TALL(NT)                                                                             \
     do {                                                                                          \
@@ -441,15 +480,18 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
             TGCN_TALL_K(NT, false, 0);                                                            \
     } while (0)
     // the two shapes of the GCN layers get fully unrolled k-loops (hidden width 200, class width 64)
+    auto finish = [&]() -> int {
+        TGCN_HIP_CHECK(hipGetLastError());
+        if constexpr (COLSUM) return launch_colsum_final(colpart, grid_used, n, colsum, s);
+        return TGCN_OK;
+    };
     if (!TRANS_B && k == 200 && nt == 2) {
         TGCN_TALL_K(2, true, 25);
-        TGCN_HIP_CHECK(hipGetLastError());
-        return TGCN_OK;
+        return finish();
     }
     if (TRANS_B && k == 64 && nt == 7) {
         TGCN_TALL_K(7, true, 8);
-        TGCN_HIP_CHECK(hipGetLastError());
-        return TGCN_OK;
+        return finish();
     }
     switch (nt) {
         case 1: TGCN_TALL(1); break;
@@ -463,8 +505,7 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
     }
 #undef TGCN_TALL
 #undef TGCN_TALL_K
-    TGCN_HIP_CHECK(hipGetLastError());
-    return TGCN_OK;
+    return finish();
 }
 
 int check_common(const char *fn, const void *a, const void *b, const void *c, int64_t N, int k, int n) {
@@ -496,15 +537,22 @@ static int gemm_nn_impl(const char *fn, const float *A, int64_t lda, const float
 }
 
 static int gemm_nt_impl(const char *fn, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
-                        int64_t ldc, int64_t N, int k, int n, const tgcn::Drop *drop, tgcn_stream stream) {
+                        int64_t ldc, int64_t N, int k, int n, const tgcn::Drop *drop, tgcn_stream stream,
+                        float *colsum = nullptr, float *colpart = nullptr) {
     using namespace tgcn;
     TGCN_CHECK(check_common(fn, A, B, C, N, k, n));
     if (lda < k || ldb < k || ldc < n || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) {
         set_error("%s: need lda, ldb >= k, ldc >= n, lda %% 4 == 0 and A 16-byte aligned", fn);
         return TGCN_E_INVALID;
     }
-    if (N == 0) return TGCN_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        if (colsum) TGCN_HIP_CHECK(hipMemsetAsync(colsum, 0, sizeof(float) * n, s));
+        return TGCN_OK;
+    }
+    if (colsum)
+        return drop ? launch_tall<true, true, true>(A, lda, B, ldb, C, ldc, N, k, n, *drop, s, colpart, colsum)
+                    : launch_tall<true, false, true>(A, lda, B, ldb, C, ldc, N, k, n, Drop{}, s, colpart, colsum);
     return drop ? launch_tall<true, true>(A, lda, B, ldb, C, ldc, N, k, n, *drop, s)
                 : launch_tall<true, false>(A, lda, B, ldb, C, ldc, N, k, n, Drop{}, s);
 }
@@ -549,6 +597,26 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
     tgcn::Drop d{};
     TGCN_CHECK(make_drop("tgcn_gemm_nt_dropout", p, seed, n, d));
     return gemm_nt_impl("tgcn_gemm_nt_dropout", A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
+}
+
+size_t tgcn_gemm_nt_colsum_workspace_bytes(int n) {
+    return n > 0 ? sizeof(float) * static_cast<size_t>(tgcn::kTallMaxGrid) * static_cast<size_t>(n) : 0;
+}
+
+int tgcn_gemm_nt_colsum(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                        int64_t N, int k, int n, double p, const uint64_t *seed, float *colsum, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream) {
+    const char *fn = "tgcn_gemm_nt_colsum";
+    if (!colsum || n <= 0 || !workspace || workspace_bytes < tgcn_gemm_nt_colsum_workspace_bytes(n)) {
+        tgcn::set_error("%s: colsum and a workspace of %zu bytes are required (%zu given)", fn,
+                        tgcn_gemm_nt_colsum_workspace_bytes(n), workspace_bytes);
+        return colsum && n > 0 ? TGCN_E_WORKSPACE : TGCN_E_INVALID;
+    }
+    float *colpart = static_cast<float *>(workspace);
+    if (!seed) return gemm_nt_impl(fn, A, lda, B, ldb, C, ldc, N, k, n, nullptr, stream, colsum, colpart);
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop(fn, p, seed, n, d));
+    return gemm_nt_impl(fn, A, lda, B, ldb, C, ldc, N, k, n, &d, stream, colsum, colpart);
 }
 
 size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {

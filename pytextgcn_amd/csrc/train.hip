@@ -24,22 +24,29 @@ constexpr int kCeBlocks = 2048;
 // iteration (independent dependency chains: the kernel is latency-bound, not bandwidth-bound).  For
 // C <= 4 LPR (always true for C <= 256) a lane keeps its <= 4 logits in registers: one read of the row,
 // one expf per element, shared by the loss and the gradient.
-template <int LPR>
+// V4 (C, ld, ldd multiples of 4, 16-byte aligned rows): the lane's four logits are CONSECUTIVE columns -- one
+// 16-byte load and one 16-byte store per lane and row; otherwise they are LPR columns apart (4-byte accesses).
+// colpart != nullptr (register path only): the workgroup also leaves the column sums of the gradient rows it
+// wrote -- the bias gradient of the layer that produced the logits -- in colpart[blockIdx.x][0..C).
+template <int LPR, bool V4>
 __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ logits, int64_t ld, int C,
                                                    const int64_t *__restrict__ target,
                                                    const uint8_t *__restrict__ mask, int64_t n_rows,
                                                    float inv_count, float *__restrict__ dlogits,
                                                    int64_t ldd, float *__restrict__ partial,
-                                                   int64_t *__restrict__ pred) {
+                                                   int64_t *__restrict__ pred, float *__restrict__ colpart) {
     constexpr int RPW = 64 / LPR;
     constexpr int KPL = 4;       // logits per lane on the register path
     constexpr int UN = 2;        // row groups in flight per wave
     __shared__ float red[4];
+    __shared__ float cred[4][LPR * KPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
     const int64_t rows_per_iter = int64_t(gridDim.x) * 4 * RPW * UN;
     const bool in_regs = C <= KPL * LPR;
+    auto col = [&](int k) { return V4 ? sl * KPL + k : sl + k * LPR; };
     float loss = 0.f;
+    float cs[KPL] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * RPW * UN; r0 < n_rows; r0 += rows_per_iter) {
         if (in_regs) {
             float x[UN][KPL];
@@ -52,10 +59,17 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                 on[u] = valid[u] && mask[r[u]] != 0;
                 const float *row = logits + (valid[u] ? r[u] : 0) * ld;
                 t[u] = on[u] ? target[r[u]] : 0;
+                const bool need = on[u] || (pred != nullptr && valid[u]);
+                if constexpr (V4) {
+                    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    if (need && sl * KPL < C) v = *reinterpret_cast<const float4 *>(row + sl * KPL);
+                    x[u][0] = v.x, x[u][1] = v.y, x[u][2] = v.z, x[u][3] = v.w;
+                } else {
 #pragma unroll
-                for (int k = 0; k < KPL; ++k) {
-                    const int c = sl + k * LPR;
-                    x[u][k] = ((on[u] || (pred != nullptr && valid[u])) && c < C) ? row[c] : -INFINITY;
+                    for (int k = 0; k < KPL; ++k) {
+                        const int c = col(k);
+                        x[u][k] = (need && c < C) ? row[c] : -INFINITY;
+                    }
                 }
             }
 #pragma unroll
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                     int bi = INT32_MAX;
 #pragma unroll
                     for (int k = KPL - 1; k >= 0; --k)
-                        if (x[u][k] == m) bi = sl + k * LPR;
+                        if (x[u][k] == m) bi = col(k);
 #pragma unroll
                     for (int off = LPR / 2; off > 0; off >>= 1) bi = min(bi, __shfl_xor(bi, off, 64));
                     if (valid[u] && sl == 0) pred[r[u]] = bi == INT32_MAX ? 0 : bi;
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                     // the lane that holds the target logit adds the row's loss term
 #pragma unroll
                     for (int k = 0; k < KPL; ++k)
-                        if (sl + k * LPR == t[u]) loss += lse - x[u][k];
+                        if (col(k) == t[u]) loss += lse - x[u][k];
                     // a class index outside [0, C) poisons the loss instead of being dropped silently
                     // (torch raises; the Python wrapper checks the labels once per tensor)
                     if (sl == 0 && (t[u] < 0 || t[u] >= C)) loss = NAN;
@@ -94,10 +108,19 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                 if (dlogits != nullptr && valid[u]) {
                     float *drow = dlogits + r[u] * ldd;
                     const float inv = on[u] ? 1.f / sum : 0.f;
+                    float d[KPL];
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
-                        const int c = sl + k * LPR;
-                        if (c < C) drow[c] = on[u] ? (e[k] * inv - (c == t[u] ? 1.f : 0.f)) * inv_count : 0.f;
+                        const int c = col(k);
+                        d[k] = (on[u] && c < C) ? (e[k] * inv - (c == t[u] ? 1.f : 0.f)) * inv_count : 0.f;
+                        cs[k] += d[k];
+                    }
+                    if constexpr (V4) {
+                        if (sl * KPL < C) *reinterpret_cast<float4 *>(drow + sl * KPL) = make_float4(d[0], d[1], d[2], d[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < KPL; ++k)
+                            if (col(k) < C) drow[col(k)] = d[k];
                     }
                 }
             }
@@ -147,8 +170,33 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
     if (lane == 0) red[wave] = loss;
+    if (colpart != nullptr) {
+        // column sums of the gradient rows: the sub-groups of a wave, then the four waves, in a fixed order
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) cs[k] += __shfl_xor(cs[k], off, 64);
+            if (sub == 0) cred[wave][sl * KPL + k] = cs[k];
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (colpart != nullptr && wave == 0 && sub == 0) {
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            const int c = col(k), i = sl * KPL + k;
+            if (c < C) colpart[int64_t(blockIdx.x) * C + c] = (cred[0][i] + cred[1][i]) + (cred[2][i] + cred[3][i]);
+        }
+    }
+}
+
+// x *= *scale unless the device scalar is exactly 1 (the seed `loss.backward()` hands to the loss node): the
+// multiplication by 1.0f is the identity bit for bit, so skipping the pass changes nothing.
+__global__ __launch_bounds__(256) void k_scale_unless_one(float *__restrict__ x, int64_t n, const float *__restrict__ scale) {
+    const float s = *scale;
+    if (s == 1.0f) return;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) x[i] *= s;
 }
 
 __global__ void k_ce_final(const float *__restrict__ partial, int n, float inv_count,
@@ -261,38 +309,95 @@ int tgcn_masked_ce(const float *logits, int64_t ld, int64_t n_rows, int n_classe
                                nullptr, workspace, workspace_bytes, stream);
 }
 
-int tgcn_masked_ce_pred(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
-                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
-                        float *dlogits, int64_t ldd, int64_t *pred, void *workspace,
-                        size_t workspace_bytes, tgcn_stream stream) {
+static int masked_ce_impl(const char *who, const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                          const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                          float *dlogits, int64_t ldd, float *dbias, int64_t *pred, void *workspace,
+                          size_t workspace_bytes, size_t workspace_need, tgcn_stream stream) {
     using namespace tgcn;
     if (!logits || !target || !mask || !loss || n_rows < 0 || n_classes <= 0 || ld < n_classes ||
-        (dlogits && ldd < n_classes)) {
-        set_error("tgcn_masked_ce: bad argument (n_rows=%lld C=%d ld=%lld)", (long long)n_rows,
-                  n_classes, (long long)ld);
+        (dlogits && ldd < n_classes) || (dbias && !dlogits)) {
+        set_error("%s: bad argument (n_rows=%lld C=%d ld=%lld)", who, (long long)n_rows, n_classes, (long long)ld);
         return TGCN_E_INVALID;
     }
-    if (!workspace || workspace_bytes < tgcn_masked_ce_workspace_bytes()) {
-        set_error("tgcn_masked_ce: workspace of %zu bytes given, %zu needed", workspace_bytes,
-                  tgcn_masked_ce_workspace_bytes());
+    if (!workspace || workspace_bytes < workspace_need) {
+        set_error("%s: workspace of %zu bytes given, %zu needed", who, workspace_bytes, workspace_need);
         return TGCN_E_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *partial = static_cast<float *>(workspace);
-    int64_t rows_per_block = 2 * 4 * (n_classes <= 16 ? 16 : n_classes <= 32 ? 8 : n_classes <= 64 ? 4 : n_classes <= 128 ? 2 : 1);
+    const int C = n_classes;
+    int64_t rows_per_block = 2 * 4 * (C <= 16 ? 16 : C <= 32 ? 8 : C <= 64 ? 4 : C <= 128 ? 2 : 1);
     int grid = static_cast<int>(std::min<int64_t>(kCeBlocks, std::max<int64_t>(1, (n_rows + rows_per_block - 1) / rows_per_block)));
-    if (n_classes <= 16)
-        k_masked_ce<4><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
-    else if (n_classes <= 32)
-        k_masked_ce<8><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
-    else if (n_classes <= 64)
-        k_masked_ce<16><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
-    else if (n_classes <= 128)
-        k_masked_ce<32><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
+    const bool v4 = C % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0 &&
+                    (!dlogits || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dlogits) % 16 == 0));
+    // the column sums ride along on the register path (C <= 256); wider rows take a separate pass below
+    float *colpart = (dbias && C <= 256) ? partial + kCeBlocks : nullptr;
+#define TGCN_CE(LPR)                                                                                                   \
+    do {                                                                                                               \
+        if (v4)                                                                                                        \
+            k_masked_ce<LPR, true><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits, ldd,   \
+                                                        partial, pred, colpart);                                       \
+        else                                                                                                           \
+            k_masked_ce<LPR, false><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits, ldd,  \
+                                                         partial, pred, colpart);                                      \
+    } while (0)
+    if (C <= 16)
+        TGCN_CE(4);
+    else if (C <= 32)
+        TGCN_CE(8);
+    else if (C <= 64)
+        TGCN_CE(16);
+    else if (C <= 128)
+        TGCN_CE(32);
     else
-        k_masked_ce<64><<<grid, 256, 0, s>>>(logits, ld, n_classes, target, mask, n_rows, inv_count, dlogits, ldd, partial, pred);
+        TGCN_CE(64);
+#undef TGCN_CE
     TGCN_HIP_CHECK(hipGetLastError());
     k_ce_final<<<1, 256, 0, s>>>(partial, grid, inv_count, loss);
+    TGCN_HIP_CHECK(hipGetLastError());
+    if (dbias) {
+        if (colpart) return launch_colsum_final(colpart, grid, C, dbias, s);
+        return launch_colsum(dlogits, ldd, n_rows, C, dbias, partial + kCeBlocks, colsum_blocks(n_rows), s);
+    }
+    return TGCN_OK;
+}
+
+int tgcn_masked_ce_pred(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                        float *dlogits, int64_t ldd, int64_t *pred, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream) {
+    return masked_ce_impl("tgcn_masked_ce", logits, ld, n_rows, n_classes, target, mask, inv_count, loss, dlogits, ldd,
+                          nullptr, pred, workspace, workspace_bytes, tgcn_masked_ce_workspace_bytes(), stream);
+}
+
+size_t tgcn_masked_ce_grad_workspace_bytes(int64_t n_rows, int n_classes) {
+    if (n_rows < 0 || n_classes <= 0) return 0;
+    const size_t rows = std::max<size_t>(tgcn::kCeBlocks, static_cast<size_t>(tgcn::colsum_blocks(n_rows)));
+    return sizeof(float) * (tgcn::kCeBlocks + rows * static_cast<size_t>(n_classes));
+}
+
+int tgcn_masked_ce_grad(const float *logits, int64_t ld, int64_t n_rows, int n_classes,
+                        const int64_t *target, const uint8_t *mask, float inv_count, float *loss,
+                        float *dlogits, int64_t ldd, float *dbias, int64_t *pred, void *workspace,
+                        size_t workspace_bytes, tgcn_stream stream) {
+    if (!dlogits || !dbias) {
+        tgcn::set_error("tgcn_masked_ce_grad: dlogits and dbias are required (use tgcn_masked_ce for the loss alone)");
+        return TGCN_E_INVALID;
+    }
+    return masked_ce_impl("tgcn_masked_ce_grad", logits, ld, n_rows, n_classes, target, mask, inv_count, loss, dlogits,
+                          ldd, dbias, pred, workspace, workspace_bytes,
+                          tgcn_masked_ce_grad_workspace_bytes(n_rows, n_classes), stream);
+}
+
+int tgcn_scale_by_device_scalar(float *x, int64_t n, const float *scale_dev, tgcn_stream stream) {
+    using namespace tgcn;
+    if (n < 0 || (n > 0 && !x) || !scale_dev) {
+        set_error("tgcn_scale_by_device_scalar: bad argument (n=%lld)", (long long)n);
+        return TGCN_E_INVALID;
+    }
+    if (n == 0) return TGCN_OK;
+    const int grid = static_cast<int>(std::min<int64_t>(4096, (n + 255) / 256));
+    k_scale_unless_one<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, n, scale_dev);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }

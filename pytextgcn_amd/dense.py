@@ -53,14 +53,27 @@ def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor
     return c
 
 
-def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
-    """a [N, k] @ b[n, k]^T; with `seed` the [N, n] result is masked and scaled (dropout backward)."""
+def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_colsums: bool = False) -> Tensor:
+    """a [N, k] @ b[n, k]^T; with `seed` the [N, n] result is masked and scaled (dropout backward).
+    `note_colsums`: the kernel also sums the columns of the result it stores and the sums are recorded for
+    `plan.colsum` (the result is a gradient on its way to a layer with a bias)."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(0)
     c = torch.empty(N, n, dtype=torch.float32, device=a.device)
     args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
+    if note_colsums:
+        from .plan import note_colsum
+        if seed is not None:
+            _check_seed(seed, a.device)
+        sums = torch.empty(n, dtype=torch.float32, device=a.device)
+        ws_bytes = lib.tgcn_gemm_nt_colsum_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        _lib.check(lib.tgcn_gemm_nt_colsum(*args, float(p), seed.data_ptr() if seed is not None else None,
+                                           sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
+        note_colsum(c, sums)
+        return c
     if seed is None:
         _lib.check(lib.tgcn_gemm_nt(*args, _stream_ptr(a.device)))
     else:
@@ -100,7 +113,7 @@ class _XW(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         x, w = ctx.saved_tensors
-        dx = gemm_nt(g, w) if ctx.needs_input_grad[0] else None        # g @ w^T
+        dx = gemm_nt(g, w, note_colsums=True) if ctx.needs_input_grad[0] else None        # g @ w^T
         dw = gemm_tn(x, g) if ctx.needs_input_grad[1] else None        # x^T @ g
         return dx, dw
 
@@ -117,7 +130,7 @@ class _XWDropout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         x, w, seed = ctx.saved_tensors
-        dx = gemm_nt(g, w, ctx.p, seed) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
+        dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
         dw = gemm_tn(x, g, ctx.p, seed) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
         return dx, dw, None, None
 

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .plan import _require_cuda, _stream_ptr
+from .plan import _require_cuda, _stream_ptr, note_colsum
 
 _COUNT_CACHE: dict = {}
 
@@ -84,24 +84,41 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count
         count = _mask_count(mask)
     inv = 1.0 / count if count else float("nan")          # torch: mean over an empty selection = nan
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
-    dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device) if want_grad else None
     pred = torch.empty(n, dtype=torch.int64, device=logits.device) if want_pred else None
+    if want_grad:
+        # loss, gradient and the column sums of the gradient (the last layer's bias gradient) in one pass
+        dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device)
+        dbias = torch.empty(C, dtype=torch.float32, device=logits.device)
+        ws_bytes = lib.tgcn_masked_ce_grad_workspace_bytes(n, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
+        _lib.check(lib.tgcn_masked_ce_grad(
+            logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(), mask.data_ptr(),
+            ctypes.c_float(inv), loss.data_ptr(), dlogits.data_ptr(), C, dbias.data_ptr(),
+            pred.data_ptr() if pred is not None else None,
+            ws.data_ptr(), ws_bytes, _stream_ptr(logits.device)))
+        return loss, (dlogits, dbias), pred
     ws_bytes = lib.tgcn_masked_ce_workspace_bytes()
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
     _lib.check(lib.tgcn_masked_ce_pred(
         logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(), mask.data_ptr(),
-        ctypes.c_float(inv), loss.data_ptr(),
-        dlogits.data_ptr() if dlogits is not None else None, C,
+        ctypes.c_float(inv), loss.data_ptr(), None, C,
         pred.data_ptr() if pred is not None else None,
         ws.data_ptr(), ws_bytes, _stream_ptr(logits.device)))
-    return loss, dlogits, pred
+    return loss, None, pred
+
+
+def _scale_by_device_scalar(x: Tensor, scale: Tensor) -> None:
+    """x *= scale for a one-element float32 device tensor `scale`; a no-op on the device when it is exactly 1."""
+    _lib.check(_lib.load().tgcn_scale_by_device_scalar(x.data_ptr(), x.numel(), scale.data_ptr(),
+                                                       _stream_ptr(x.device)))
+    torch.autograd.graph.increment_version(x)
 
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count, want_pred: bool):
-        loss, dlogits, pred = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count, want_pred)
-        ctx.save_for_backward(dlogits)
+        loss, grads, pred = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count, want_pred)
+        ctx.save_for_backward(*(grads if grads is not None else ()))
         if not want_pred:
             return loss
         ctx.mark_non_differentiable(pred)
@@ -109,14 +126,23 @@ class _MaskedCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out: Tensor, *_):
-        (dlogits,) = ctx.saved_tensors
+        dlogits, dbias = ctx.saved_tensors
         # dlogits is ours: scale it in place (no second N x C pass) -- which makes this node single-use:
         # a second backward through it (retain_graph=True) would compound the scale, so it is refused
         if getattr(ctx, "_tgcn_used", False):
             raise RuntimeError("masked_cross_entropy: backward was already run through this loss (its gradient "
                                "buffer is scaled in place); recompute the loss instead of retain_graph=True")
         ctx._tgcn_used = True
-        return dlogits.mul_(grad_out), None, None, None, None
+        if grad_out.is_cuda and grad_out.dtype == torch.float32 and grad_out.numel() == 1:
+            # `loss.backward()` seeds this node with 1: the kernel reads the scalar and leaves at once
+            _scale_by_device_scalar(dlogits, grad_out)
+            _scale_by_device_scalar(dbias, grad_out)
+        else:
+            dlogits.mul_(grad_out)
+            dbias.mul_(grad_out)
+        # the layer that produced the logits finds its bias gradient ready (plan.colsum)
+        note_colsum(dlogits, dbias)
+        return dlogits, None, None, None, None
 
 
 def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Tensor, count=None, return_pred: bool = False):

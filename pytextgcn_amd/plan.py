@@ -227,8 +227,36 @@ def _spmm_adam(self, g: Tensor, param: Tensor, exp_avg: Tensor, exp_avg_sq: Tens
 GraphPlan.spmm_adam = _spmm_adam
 
 
+# Column sums a producer kernel already took while it wrote the matrix (tgcn_masked_ce_grad: the gradient of the
+# logits; tgcn_gemm_nt*: the gradient of the hidden activation).  Keyed by storage address, validated by a weak
+# reference to the producing tensor (alive => the address was not recycled), its shape and its version counter.
+_KNOWN_COLSUMS: dict = {}
+
+
+def note_colsum(t: Tensor, sums: Tensor) -> None:
+    """Record `sums == t.sum(0)` for the tensor `t` as it is now (any later in-place edit invalidates the note)."""
+    import weakref
+    key = t.data_ptr()
+    _KNOWN_COLSUMS[key] = (weakref.ref(t, lambda _, k=key: _KNOWN_COLSUMS.pop(k, None)), tuple(t.shape), t._version, sums)
+
+
+def _known_colsum(g: Tensor) -> Optional[Tensor]:
+    hit = _KNOWN_COLSUMS.get(g.data_ptr())
+    if hit is None:
+        return None
+    t = hit[0]()
+    if t is None or t.data_ptr() != g.data_ptr() or hit[1] != tuple(g.shape) or hit[2] != g._version \
+            or t._version != g._version or not g.is_contiguous():
+        return None
+    return hit[3]
+
+
 def colsum(g: Tensor) -> Tensor:
-    """Column sums of a float32 [n, F] device matrix (the bias gradient), deterministic."""
+    """Column sums of a float32 [n, F] device matrix (the bias gradient), deterministic.  A matrix whose producer
+    kernel left its column sums (`note_colsum`) is not read again."""
+    known = _known_colsum(g)
+    if known is not None:
+        return known
     lib = _lib.load()
     _require_cuda(g, "g")
     if g.dtype != torch.float32 or g.dim() != 2:

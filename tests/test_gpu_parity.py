@@ -204,6 +204,14 @@ def test_colsum(cuda):
         assert rel_err(colsum(gmat), csr_oracle.colsum(gmat.cpu())) < TOL
     big = torch.randn(512, 300, device=cuda)
     assert rel_err(colsum(big[:, 4:204]), big[:, 4:204].double().sum(0).float()) < TOL
+    # every lane layout of the first pass (16 / 32 / 64 lanes per row, scalar columns), row counts around the
+    # unrolled loop's stride, more than one partial row per workgroup
+    for n, F in [(300_001, 64), (9, 64), (65_537, 40), (200_003, 128), (100_000, 100), (400_000, 200), (70_001, 260), (50_000, 7)]:
+        gmat = torch.randn(n, F, device=cuda) + 0.25
+        ref = gmat.double().sum(0)
+        assert ((colsum(gmat).double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item() < 1e-5, (n, F)
+    a = colsum(torch.ones(123_457, 64, device=cuda))
+    assert torch.equal(a, torch.full((64,), 123_457.0, device=cuda))           # exact: nothing dropped, nothing twice
 
 
 # ------------------------------------------------------------------------------------------------
@@ -445,6 +453,49 @@ def test_masked_cross_entropy_matches_torch(cuda, n, C):
     a = masked_cross_entropy(big[:, 2:2 + C], y.to(cuda), mask.to(cuda))
     b = torch.nn.functional.cross_entropy(big[:, 2:2 + C].cpu()[mask], y[mask])
     assert abs(a.item() - b.item()) < TOL * abs(b.item()) + 1e-7
+
+
+@pytest.mark.parametrize("n,C,scale", [(5000, 64, 1.0), (5000, 64, 2.5), (3001, 20, 1.0), (777, 7, 0.5), (2000, 129, 1.0),
+                                       (900, 256, 1.0), (300, 300, 3.0), (70_000, 64, 1.0)])
+def test_masked_cross_entropy_leaves_the_bias_gradient(cuda, n, C, scale):
+    """tgcn_masked_ce_grad: the column sums of the gradient (the bias gradient of the layer that produced the
+    logits) come out of the same pass; `plan.colsum` finds them instead of reading dlogits again -- also when
+    the loss is scaled before backward (the chain rule through tgcn_scale_by_device_scalar), and not any more
+    once the gradient buffer was edited."""
+    from pytextgcn_amd import plan as plan_mod
+    from pytextgcn_amd.functional import masked_cross_entropy
+    gen = torch.Generator().manual_seed(n + C)
+    logits = (torch.randn(n, C, generator=gen) * 2).to(cuda)
+    y = torch.randint(0, C, (n,), generator=gen).to(cuda)
+    mask = (torch.rand(n, generator=gen) < 0.5).to(cuda)
+    seen = {}
+
+    class Probe(torch.autograd.Function):          # stands where the last GCNConv's propagate node stands
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["g"] = g
+            seen["known"] = plan_mod._known_colsum(g)
+            seen["colsum"] = plan_mod.colsum(g)
+            return g
+
+    lg = logits.clone().requires_grad_()
+    loss = masked_cross_entropy(Probe.apply(lg), y, mask)
+    (loss * scale if scale != 1.0 else loss).backward()
+    ref = logits.cpu().double().requires_grad_()
+    (torch.nn.functional.cross_entropy(ref[mask.cpu()], y.cpu()[mask.cpu()]) * scale).backward()
+    assert rel_err(lg.grad, ref.grad.float()) < TOL
+    assert seen["known"] is not None and seen["colsum"] is seen["known"]
+    want = ref.grad.sum(0)
+    assert ((seen["colsum"].cpu().double() - want).abs().max() / want.abs().max()).item() < 2e-5
+    # and against the gradient actually written (same numbers, another summation order)
+    assert rel_err(seen["colsum"], seen["g"].double().sum(0).float()) < 2e-5
+    seen["g"].add_(1.0)                                           # an edit invalidates the note
+    assert plan_mod._known_colsum(seen["g"]) is None
+    assert rel_err(plan_mod.colsum(seen["g"]), seen["g"].double().sum(0).float()) < TOL
 
 
 @pytest.mark.parametrize("amsgrad,wd", [(True, 0.0), (False, 0.0), (True, 0.01)])
@@ -690,6 +741,27 @@ def test_mfma_gemms_match_float64(cuda, N, k, n):
     assert rel_err(dense.gemm_tn(ad, gd), (a.double().t() @ g.double()).float()) < TOL
     big = torch.randn(N, k + 8, generator=gen).to(cuda)                    # strided A
     assert rel_err(dense.gemm_nn(big[:, 4:4 + k], bd), (big[:, 4:4 + k].cpu().double() @ b.double()).float()) < TOL
+
+
+@pytest.mark.parametrize("N,k,n,p", [(1, 1, 1, 0.0), (31, 7, 3, 0.5), (1000, 64, 200, 0.0), (4097, 10, 200, 0.7),
+                                     (100_000, 64, 200, 0.5), (5000, 64, 256, 0.5), (70_001, 32, 100, 0.0)])
+def test_nt_gemm_leaves_the_column_sums_of_its_result(cuda, N, k, n, p):
+    """tgcn_gemm_nt_colsum: dH1 = (mask *) dXW2 @ W2^T together with its column sums (the first layer's bias
+    gradient).  The product itself is bit for bit the one of tgcn_gemm_nt / _nt_dropout; the sums agree with a
+    float64 sum of the stored result and are what `plan.colsum` returns for that tensor."""
+    from pytextgcn_amd import dense, plan as plan_mod
+    gen = torch.Generator().manual_seed(N + k + n)
+    a = torch.randn(N, (k + 3) // 4 * 4, generator=gen).to(cuda)[:, :k]
+    b = torch.randn(n, k, generator=gen).to(cuda)
+    seed = dense.new_seed(cuda) if p > 0 else None
+    plain = dense.gemm_nt(a, b, p, seed)
+    noted = dense.gemm_nt(a, b, p, seed, note_colsums=True)
+    assert torch.equal(plain, noted)
+    sums = plan_mod._known_colsum(noted)
+    assert sums is not None and plan_mod.colsum(noted) is sums
+    ref = noted.double().sum(0)
+    assert ((sums.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item() < 2e-5
+    assert plan_mod._known_colsum(plain) is None
 
 
 def test_dense_layer_autograd_uses_the_mfma_kernels(cuda):

@@ -45,3 +45,22 @@ for name, mine, ref in [
 ]:
     a, b = t(mine), t(ref)
     print(f"{name} fused {a:7.3f} ms   unfused (separate elementwise pass where there is one) {b:7.3f} ms")
+
+# nt with the column sums of the result taken in the epilogue (tgcn_gemm_nt_colsum) against product + tgcn_colsum
+from pytextgcn_amd.plan import colsum  # noqa: E402
+Wt = torch.randn(h, C, device=dev)          # [n = h, k = C]
+for name, mine, ref in [
+    ("nt + column sums, no mask   ", lambda: dense.gemm_nt(G, Wt, note_colsums=True), lambda: colsum(dense.gemm_nt(G, Wt))),
+    ("nt + column sums, dropout   ", lambda: dense.gemm_nt(G, Wt, 0.5, seed, note_colsums=True), lambda: colsum(dense.gemm_nt(G, Wt, 0.5, seed))),
+]:
+    a, b = t(mine), t(ref)
+    print(f"{name} fused {a:7.3f} ms   product then tgcn_colsum {b:7.3f} ms")
+for F in (200, 64):
+    M = torch.randn(N, F, device=dev)
+    print(f"tgcn_colsum [{N} x {F}]: {t(lambda: colsum(M)):7.3f} ms")
+from pytextgcn_amd.functional import masked_cross_entropy  # noqa: E402
+y = torch.randint(0, C, (N,), device=dev)
+mask = torch.rand(N, device=dev) < 0.7
+lg = torch.randn(N, C, device=dev, requires_grad=True)
+print(f"masked CE, loss + predictions (eval): {t(lambda: masked_cross_entropy(lg.detach(), y, mask, return_pred=True)):7.3f} ms")
+print(f"masked CE, loss + gradient + bias gradient (train forward): {t(lambda: masked_cross_entropy(lg, y, mask)):7.3f} ms")
