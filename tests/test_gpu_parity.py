@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI (pytextgcn_amd -> ctypes -> libtgcn.so),
 against the CPU oracle on identical inputs.  Tolerance is BASELINE.json's: 1e-5 relative fp32,
 measured as max|a-b| / max|b|; index arrays must match exactly."""
+import ctypes
 import os
 
 import numpy as np
@@ -327,6 +328,30 @@ def test_error_behaviour(cuda):
         plan.spmm(torch.ones(10, 4, device=cuda, dtype=torch.float64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         plan.spmm(torch.ones(10, 4))
+    # status codes of the round-2 entry points, straight at the C ABI
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    lg, dl, db = torch.zeros(8, 4, device=cuda), torch.zeros(8, 4, device=cuda), torch.zeros(4, device=cuda)
+    y, mk, loss = torch.zeros(8, dtype=torch.int64, device=cuda), torch.ones(8, dtype=torch.bool, device=cuda), torch.zeros((), device=cuda)
+    ws = torch.empty(lib.tgcn_masked_ce_grad_workspace_bytes(8, 4), dtype=torch.uint8, device=cuda)
+    args = (lg.data_ptr(), 4, 8, 4, y.data_ptr(), mk.data_ptr(), ctypes.c_float(0.125), loss.data_ptr(), dl.data_ptr(), 4)
+    assert lib.tgcn_masked_ce_grad(*args, db.data_ptr(), None, ws.data_ptr(), ws.numel(), s) == _lib.OK
+    assert lib.tgcn_masked_ce_grad(*args, None, None, ws.data_ptr(), ws.numel(), s) == _lib.E_INVALID       # dbias is the point
+    assert lib.tgcn_masked_ce_grad(*args, db.data_ptr(), None, ws.data_ptr(), 16, s) == _lib.E_WORKSPACE
+    assert b"workspace" in lib.tgcn_last_error()
+    assert lib.tgcn_scale_by_device_scalar(dl.data_ptr(), dl.numel(), None, s) == _lib.E_INVALID
+    assert lib.tgcn_scale_by_device_scalar(None, 0, loss.data_ptr(), s) == _lib.OK                         # nothing to scale
+    a, bm, c = torch.zeros(8, 4, device=cuda), torch.zeros(5, 4, device=cuda), torch.zeros(8, 5, device=cuda)
+    cs = torch.zeros(5, device=cuda)
+    w2 = torch.empty(lib.tgcn_gemm_nt_colsum_workspace_bytes(5), dtype=torch.uint8, device=cuda)
+    nt = (a.data_ptr(), 4, bm.data_ptr(), 4, c.data_ptr(), 5, 8, 4, 5, 0.0, None)
+    assert lib.tgcn_gemm_nt_colsum(*nt, cs.data_ptr(), w2.data_ptr(), w2.numel(), s) == _lib.OK
+    assert lib.tgcn_gemm_nt_colsum(*nt, None, w2.data_ptr(), w2.numel(), s) == _lib.E_INVALID
+    assert lib.tgcn_gemm_nt_colsum(*nt, cs.data_ptr(), w2.data_ptr(), 8, s) == _lib.E_WORKSPACE
+    cs.fill_(7.0)
+    assert lib.tgcn_gemm_nt_colsum(a.data_ptr(), 4, bm.data_ptr(), 4, c.data_ptr(), 5, 0, 4, 5, 0.0, None, cs.data_ptr(),
+                                   w2.data_ptr(), w2.numel(), s) == _lib.OK
+    assert torch.equal(cs, torch.zeros(5, device=cuda))                      # no rows: the sums are zero, not stale
 
 
 # ------------------------------------------------------------------------------------------------
