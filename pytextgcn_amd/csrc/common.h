@@ -84,6 +84,11 @@ struct CsrBlock {
     int2 *sweep_cv = nullptr;   // [sweep_nnz]
     int32_t *sweep_ptr = nullptr;  // [8 * 512 + 1]
     int32_t *sweep_out = nullptr;  // [n_sweep] local row -> its carry row for label 0, relative to sweep_slot_base (-1: unused)
+    // The rows of every row block in order of falling degree (plan.hip: build_items), as {first entry, end, row, 0}:
+    // the sub-group kernels hand the rows of a block to their 4 (2) sub-groups in THIS order, so that the rows a
+    // wave sums side by side have about the same length (a wave runs as many gather rounds as its longest row
+    // needs); one 16-byte load replaces the two row-pointer loads, the dependent chain stays three loads long.
+    int4 *row_info = nullptr;   // [n_rows]
     WorkItem *items_all = nullptr;
     int32_t n_items_all = 0;
     FixEntry *fix_all = nullptr;

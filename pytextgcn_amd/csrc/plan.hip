@@ -433,6 +433,7 @@ void free_block(CsrBlock &b) {
     if (b.cv) (void)hipFree(b.cv);
     if (b.items) (void)hipFree(b.items);
     if (b.fix) (void)hipFree(b.fix);
+    if (b.row_info) (void)hipFree(b.row_info);
     if (b.items_all) (void)hipFree(b.items_all);
     if (b.fix_all) (void)hipFree(b.fix_all);
     if (b.hot_vals) (void)hipFree(b.hot_vals);
@@ -485,6 +486,32 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             }
         }
         if (r0 < n_rows) blocks.push_back({r0, n_rows, rp[r0], rp[n_rows]});
+    }
+    // rows of each block by falling degree (stable: equal degrees keep row order), for the sub-group kernels
+    static const bool sort_rows = [] {
+        const char *e = std::getenv("TGCN_ROW_SORT");
+        return e ? std::atoi(e) != 0 : true;
+    }();
+    if (b.row_info) {
+        (void)hipFree(b.row_info);
+        b.row_info = nullptr;
+    }
+    if (n_rows > 0) {
+        std::vector<int32_t> perm(static_cast<size_t>(n_rows));
+        for (int32_t r = 0; r < n_rows; ++r) perm[r] = r;
+        if (sort_rows)
+            for (const WorkItem &it : blocks)
+                if (it.row_end - it.row_begin > 1)
+                    std::stable_sort(perm.begin() + it.row_begin, perm.begin() + it.row_end,
+                                     [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
+        std::vector<int4> info(static_cast<size_t>(n_rows));
+        for (int32_t i = 0; i < n_rows; ++i) info[i] = make_int4(rp[perm[i]], rp[perm[i] + 1], perm[i], 0);
+        DevBuf d_info;
+        TGCN_CHECK(d_info.alloc(sizeof(int4) * info.size()));
+        TGCN_HIP_CHECK(hipMemcpyAsync(d_info.p, info.data(), sizeof(int4) * info.size(), hipMemcpyHostToDevice, stream));
+        TGCN_HIP_CHECK(hipStreamSynchronize(stream));      // `info` leaves scope
+        b.bytes += d_info.bytes;
+        b.row_info = static_cast<int4 *>(d_info.release());
     }
 
     // column-block cut positions of the long rows (binary searches on the device)

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_spmm_subb(
     const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
     const int2 *__restrict__ cv, const float *__restrict__ X, unsigned ldx4 /* row stride in bytes */,
     unsigned x_bytes, int F, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy,
-    float *__restrict__ carry, int64_t ldc) {
+    float *__restrict__ carry, int64_t ldc, const int4 *__restrict__ row_info) {
     constexpr int S = 64 / G;
     static_assert(G % U == 0, "a batch of G entries is gathered in whole groups of U");
     const int lane = threadIdx.x & 63;
@@ -467,8 +467,10 @@ __global__ __launch_bounds__(256) void k_spmm_subb(
         const int slot = -it.row_end - 1;
         if (sub == 0 && active) *reinterpret_cast<float4 *>(carry + int64_t(slot) * ldc + lane_off / 4) = acc;
     } else {
-        for (int r = it.row_begin + sub; r < it.row_end; r += S) {
-            const int b = rowptr[r], e = rowptr[r + 1];
+        // rows in order of falling degree (CsrBlock::row_info): the S rows of one pass have about the same length
+        for (int i = it.row_begin + sub; i < it.row_end; i += S) {
+            const int4 ri = row_info[i];
+            const int b = ri.x, e = ri.y, r = ri.z;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (b < e) acc = run(b, 1, e);
             if (active)
@@ -829,12 +831,15 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         } else if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
             // U = 4 gathers in flight per sub-group: 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows
             // hold ~10 entries and every started group of U is gathered in full
+            // (with the rows of a block sorted by degree U = 4 is still the best: 2 / 8 measured 10 % / 8 % slower)
             if (F <= 64)
                 k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
-                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc);
+                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
+                                                            blk.row_info);
             else
                 k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
-                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc);
+                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
+                                                            blk.row_info);
         } else if (VEC == 4 && F <= 128 && narrow_from_env()) {
             // narrow feature rows (the layer-2 width C): sub-group kernel
             if (F <= 64)
