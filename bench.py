@@ -513,6 +513,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the exchange of the distributed SpMM has two forms (RCCL collectives / pairwise transfers + all-to-all,
+    # pytextgcn_amd.sharded); which one is faster depends on what RCCL makes of the xGMI mesh, so a few untimed
+    # steps of each decide (max over ranks, the same answer on every rank).  TGCN_EXCHANGE pins the form.
+    exchange_selection = None
+    if world > 1 and "TGCN_EXCHANGE" not in os.environ:
+        trial = {}
+        for mode in ("collective", "p2p"):
+            sg.exchange = mode
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[mode] = t.item()
+        sg.exchange = min(trial, key=trial.get)
+        exchange_selection = {"ms_per_step": trial, "chosen": sg.exchange}
+        parallelism = (f"row{world}: hubs(words) replicated by all-gather, hub rows reduce-scattered"
+                       f" (exchange={sg.exchange}, the faster of the two forms in {trial})")
     for _ in range(args.warmup):
         step()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -629,6 +650,7 @@ def main():
             "epoch_ms_fused_w1_update_in_backward_with_activation_reuse": epoch_ms_w1_reuse,
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
+            "exchange_selection": exchange_selection,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E)
