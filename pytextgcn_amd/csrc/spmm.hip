@@ -677,6 +677,15 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
     const float *base = carry + int64_t(fe.slot_begin) * ldc + lc;
     vec_t acc = V::zero();
     int s = wave;
+    // (the 32 hot rows hold one partial per workgroup of k_spmm_hot, 256 of them: eight loads in flight per wave;
+    // the sum runs in slot order either way)
+    for (; s + 7 * kWavesPerBlock < fe.count; s += 8 * kWavesPerBlock) {
+        vec_t a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const vec_t *>(base + int64_t(s + u * kWavesPerBlock) * ldc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = V::add(acc, a[u]);
+    }
     for (; s + 3 * kWavesPerBlock < fe.count; s += 4 * kWavesPerBlock) {
         const vec_t a0 = *reinterpret_cast<const vec_t *>(base + int64_t(s) * ldc);
         const vec_t a1 = *reinterpret_cast<const vec_t *>(base + int64_t(s + kWavesPerBlock) * ldc);

@@ -21,14 +21,14 @@ namespace {
 constexpr int kCeBlocks = 2048;
 
 // LPR lanes cooperate on one row; a wave handles 64/LPR rows at a time, two such groups per loop
-// iteration (independent dependency chains: the kernel is latency-bound, not bandwidth-bound).  For
-// C <= 4 LPR (always true for C <= 256) a lane keeps its <= 4 logits in registers: one read of the row,
-// one expf per element, shared by the loss and the gradient.
-// V4 (C, ld, ldd multiples of 4, 16-byte aligned rows): the lane's four logits are CONSECUTIVE columns -- one
-// 16-byte load and one 16-byte store per lane and row; otherwise they are LPR columns apart (4-byte accesses).
+// iteration (independent dependency chains: the kernel is instruction- and latency-bound, not bandwidth-bound).
+// For C <= KPL * LPR (the launcher's choice for C <= 256) a lane keeps its <= KPL logits in registers: one read
+// of the row, one expf per element, shared by the loss and the gradient.
+// V4 (C, ld, ldd multiples of 4, 16-byte aligned rows): the lane's KPL logits are CONSECUTIVE columns -- 16-byte
+// loads and stores; otherwise they are LPR columns apart (4-byte accesses).
 // colpart != nullptr (register path only): the workgroup also leaves the column sums of the gradient rows it
 // wrote -- the bias gradient of the layer that produced the logits -- in colpart[blockIdx.x][0..C).
-template <int LPR, bool V4>
+template <int LPR, bool V4, int KPL = 4>
 __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ logits, int64_t ld, int C,
                                                    const int64_t *__restrict__ target,
                                                    const uint8_t *__restrict__ mask, int64_t n_rows,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                                                    int64_t ldd, float *__restrict__ partial,
                                                    int64_t *__restrict__ pred, float *__restrict__ colpart) {
     constexpr int RPW = 64 / LPR;
-    constexpr int KPL = 4;       // logits per lane on the register path
+    static_assert(KPL == 4 || KPL == 8, "logits per lane on the register path");
     constexpr int UN = 2;        // row groups in flight per wave
     __shared__ float red[4];
     __shared__ float cred[4][LPR * KPL];
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
     const bool in_regs = C <= KPL * LPR;
     auto col = [&](int k) { return V4 ? sl * KPL + k : sl + k * LPR; };
     float loss = 0.f;
-    float cs[KPL] = {0.f, 0.f, 0.f, 0.f};
+    float cs[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) cs[k] = 0.f;
     for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * RPW * UN; r0 < n_rows; r0 += rows_per_iter) {
         if (in_regs) {
             float x[UN][KPL];
@@ -61,9 +63,12 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                 t[u] = on[u] ? target[r[u]] : 0;
                 const bool need = on[u] || (pred != nullptr && valid[u]);
                 if constexpr (V4) {
-                    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    if (need && sl * KPL < C) v = *reinterpret_cast<const float4 *>(row + sl * KPL);
-                    x[u][0] = v.x, x[u][1] = v.y, x[u][2] = v.z, x[u][3] = v.w;
+#pragma unroll
+                    for (int q = 0; q < KPL / 4; ++q) {
+                        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                        if (need && sl * KPL + 4 * q < C) v = *reinterpret_cast<const float4 *>(row + sl * KPL + 4 * q);
+                        x[u][4 * q] = v.x, x[u][4 * q + 1] = v.y, x[u][4 * q + 2] = v.z, x[u][4 * q + 3] = v.w;
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
@@ -75,6 +80,9 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 float m = fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3]));
+#pragma unroll
+                for (int q = 1; q < KPL / 4; ++q)
+                    m = fmaxf(m, fmaxf(fmaxf(x[u][4 * q], x[u][4 * q + 1]), fmaxf(x[u][4 * q + 2], x[u][4 * q + 3])));
 #pragma unroll
                 for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
                 if (pred != nullptr) {
@@ -116,7 +124,11 @@ __global__ __launch_bounds__(256) void k_masked_ce(const float *__restrict__ log
                         cs[k] += d[k];
                     }
                     if constexpr (V4) {
-                        if (sl * KPL < C) *reinterpret_cast<float4 *>(drow + sl * KPL) = make_float4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+                        for (int q = 0; q < KPL / 4; ++q)
+                            if (sl * KPL + 4 * q < C)
+                                *reinterpret_cast<float4 *>(drow + sl * KPL + 4 * q) =
+                                    make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
                     } else {
 #pragma unroll
                         for (int k = 0; k < KPL; ++k)
@@ -332,25 +344,44 @@ static int masked_ce_impl(const char *who, const float *logits, int64_t ld, int6
                     (!dlogits || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dlogits) % 16 == 0));
     // the column sums ride along on the register path (C <= 256); wider rows take a separate pass below
     float *colpart = (dbias && C <= 256) ? partial + kCeBlocks : nullptr;
-#define TGCN_CE(LPR)                                                                                                   \
+#define TGCN_CE(LPR, KPL)                                                                                              \
     do {                                                                                                               \
         if (v4)                                                                                                        \
-            k_masked_ce<LPR, true><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits, ldd,   \
-                                                        partial, pred, colpart);                                       \
+            k_masked_ce<LPR, true, KPL><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits,   \
+                                                             ldd, partial, pred, colpart);                             \
         else                                                                                                           \
-            k_masked_ce<LPR, false><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits, ldd,  \
-                                                         partial, pred, colpart);                                      \
+            k_masked_ce<LPR, false, KPL><<<grid, 256, 0, s>>>(logits, ld, C, target, mask, n_rows, inv_count, dlogits,  \
+                                                              ldd, partial, pred, colpart);                            \
     } while (0)
-    if (C <= 16)
-        TGCN_CE(4);
+    // Logits per lane on the register path: 8 (half the lanes per row, one shuffle level less in each of the three
+    // row reductions) measured 0.247 -> 0.149 ms without and 0.308 -> 0.232 ms with the gradient at c4 (2 M x 64);
+    // 16 was slower again (0.17 / 0.28 ms).  TGCN_CE_KPL=4 selects the round-1 layout.
+    static const int kpl = [] {
+        const char *e = std::getenv("TGCN_CE_KPL");
+        return e && std::atoi(e) == 4 ? 4 : 8;
+    }();
+    if (kpl == 8 && C > 16 && C <= 256) {
+        // eight logits per lane: half the lanes per row, one reduction level less
+        rows_per_block = 2 * 4 * (C <= 32 ? 16 : C <= 64 ? 8 : C <= 128 ? 4 : 2);
+        grid = static_cast<int>(std::min<int64_t>(kCeBlocks, std::max<int64_t>(1, (n_rows + rows_per_block - 1) / rows_per_block)));
+        if (C <= 32)
+            TGCN_CE(4, 8);
+        else if (C <= 64)
+            TGCN_CE(8, 8);
+        else if (C <= 128)
+            TGCN_CE(16, 8);
+        else
+            TGCN_CE(32, 8);
+    } else if (C <= 16)
+        TGCN_CE(4, 4);
     else if (C <= 32)
-        TGCN_CE(8);
+        TGCN_CE(8, 4);
     else if (C <= 64)
-        TGCN_CE(16);
+        TGCN_CE(16, 4);
     else if (C <= 128)
-        TGCN_CE(32);
+        TGCN_CE(32, 4);
     else
-        TGCN_CE(64);
+        TGCN_CE(64, 4);
 #undef TGCN_CE
     TGCN_HIP_CHECK(hipGetLastError());
     k_ce_final<<<1, 256, 0, s>>>(partial, grid, inv_count, loss);
