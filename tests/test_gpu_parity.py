@@ -153,6 +153,38 @@ def test_spmm_strided_operands_and_noncontiguous_edge_index(cuda):
     assert rel_err(out[:, 4:204], ref) < TOL and (out[:, :4] == 7).all() and (out[:, 204:] == 7).all()
 
 
+def test_random_small_graphs_every_kernel_family(cuda):
+    """Sixty random graphs -- sizes from one node to a few thousand, no edges to dense hubs, duplicates, explicit
+    self loops, unweighted / weighted, with and without added loops and normalisation -- at widths that reach the
+    scalar, the sub-group (16 / 32 lanes per row) and the wide kernels, forward and transposed, against the
+    oracle's gather -> scale -> scatter formulation."""
+    gen = torch.Generator().manual_seed(20260)
+    widths = [1, 3, 4, 12, 32, 64, 68, 128, 132, 200, 256, 260]
+    for case in range(60):
+        n = int(torch.randint(1, 3000, (1,), generator=gen))
+        e = int(torch.randint(0, 20 * n + 1, (1,), generator=gen)) if case % 7 else 0
+        ei = torch.randint(0, n, (2, e), generator=gen)
+        if e and case % 3 == 0:                                   # a few hubs: long rows, segments, maybe a hot block
+            hubs = torch.randint(0, n, (max(1, n // 200),), generator=gen)
+            sel = torch.rand(e, generator=gen) < 0.5
+            ei[1, sel] = hubs[torch.randint(0, hubs.numel(), (int(sel.sum()),), generator=gen)]
+        if e and case % 4 == 0:                                   # duplicates and explicit self loops
+            ei = torch.cat([ei, ei[:, : e // 3], torch.arange(0, n, 3).repeat(2, 1)], 1)
+        w = None if case % 5 == 0 else torch.rand(ei.size(1), generator=gen) + 0.05
+        add_loops, normalize = case % 6 != 1, case % 6 != 2
+        F = widths[case % len(widths)]
+        x = torch.randn(n, F, generator=gen)
+        b = torch.randn(F, generator=gen) if case % 2 else None
+        plan = GraphPlan(ei.to(cuda), None if w is None else w.to(cuda), n, add_self_loops=add_loops, normalize=normalize)
+        got = plan.spmm(x.to(cuda), None if b is None else b.to(cuda))
+        want = oracle_spmm(ei, w, n, x, b, add_self_loops=add_loops, normalize=normalize)
+        assert rel_err(got, want) < TOL, (case, n, e, F, "forward")
+        got_t = plan.spmm(x.to(cuda), transpose=True)
+        want_t = oracle_spmm(ei, w, n, x, transpose=True, add_self_loops=add_loops, normalize=normalize)
+        assert rel_err(got_t, want_t) < TOL, (case, n, e, F, "transposed")
+        plan.close()
+
+
 @pytest.mark.parametrize("F", [200, 64, 7])
 def test_long_rows_are_split_and_reduced(cuda, F):
     # a hub of degree 5000 >> item weight (384) plus rows of 513 / 512 entries (long too), among short rows
