@@ -140,6 +140,33 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "edges/s" and c["sample"]
 
 
+def test_committed_round2_bench_line_carries_a_believable_roofline():
+    """profiles/r02_bench_c4_n1.json (final round-2 library, one MI355X): the contract keys, a roofline fraction
+    in [0, 1] that is the measured HBM bytes over time over peak, the other three byte counts beside it, and both
+    CPU baseline rows of BASELINE.md section 3."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_c4_n1.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "epoch_ms", "epoch_ms_fused"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "edges/s" and d["vs_baseline"] is None and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 50_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] <= 1.0
+    launch_s = r["launch_ms"] * 1e-3
+    assert abs(r["frac"] - r["traffic"] / launch_s / 1e9 / r["peak"]) < 1e-6        # frac = measured HBM bytes / time / peak
+    assert abs(r["frac_algorithmic"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac_algorithmic"] > 1.0
+    assert r["frac_compulsory"] < r["frac"] < r["frac_traffic"] <= 1.0              # compulsory < HBM < fabric
+    assert r["hbm_activity"]["bytes_per_step"] > 0 and "mem_busy_percent" in r["traffic_basis"]
+    assert 0.0 < r["l2_resident_ceiling_ms"] < r["launch_ms"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "edges/s" and "cpu_model" in c
+    assert c["csr"]["value"] > c["value"] > 0 and c["csr"]["unit"] == "edges/s"      # CPU-ref and CPU-csr rows
+    assert d["epoch_ms_fused"] < d["epoch_ms"]
+
+
 def test_mask_count_cache_is_keyed_by_object_not_by_address():
     """A dead temporary's storage (and id) can be handed to the next mask: the cached row count must not
     follow it."""
