@@ -19,7 +19,9 @@
 // malloc'd arrays, :65-66).
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <new>
+#include <vector>
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -92,6 +94,82 @@ __global__ void k_pair_counts(const int32_t *__restrict__ X, int64_t n_docs, int
         const int64_t lo = std::max<int64_t>(0, l - w + 1);
         if (hi >= lo)
             atomicAdd(&cij[sym_diag_idx(a, b, V)], static_cast<uint32_t>(hi - lo + 1));
+    }
+}
+
+// ---- hot-pair privatisation ------------------------------------------------------------------------------
+// Word frequencies follow a Zipf law: the pairs among the most frequent words -- above all the diagonal
+// entries (a, a), one update per token -- hit a handful of addresses, and same-address atomics from all
+// XCDs serialise in one L2 channel (k_pair_counts alone: 240 M atomics in 64 ms on a 100 k-document corpus).
+// So the H most frequent words (token histogram, top-H chosen on the host) get a workgroup-private packed
+// triangle of pair counts in LDS; a workgroup walks a contiguous slice of token positions and flushes its
+// non-zero counters once.  Integer sums: the result is the same whatever the order.
+constexpr int kHotWords = 128;
+constexpr int kHotTri = kHotWords * (kHotWords + 1) / 2;
+constexpr int kHistChunk = 32768;        // vocabulary ids per pass of the token histogram (128 KB of LDS)
+
+__global__ __launch_bounds__(1024) void k_token_hist(const int32_t *__restrict__ X, int64_t n, int64_t v0, int64_t v1,
+                                                      uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t h[];
+    const int span = static_cast<int>(v1 - v0);
+    for (int j = threadIdx.x; j < span; j += blockDim.x) h[j] = 0;
+    __syncthreads();
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b = int64_t(blockIdx.x) * per, e = std::min(n, b + per);
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const int32_t a = X[i];
+        if (a >= v0 && a < v1) atomicAdd(&h[a - v0], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < span; j += blockDim.x)
+        if (h[j] != 0) atomicAdd(&hist[v0 + j], h[j]);
+}
+
+// the kernel above with the pairs of hot words counted in LDS; hot_of[word] = hot index or -1
+__global__ __launch_bounds__(256) void k_pair_counts_hot(const int32_t *__restrict__ X, int64_t n_docs, int64_t L, int64_t w,
+                                                         int64_t V, const int32_t *__restrict__ last_start,
+                                                         const int16_t *__restrict__ hot_of,
+                                                         const int32_t *__restrict__ hot_word, uint32_t *__restrict__ cij) {
+    __shared__ uint32_t tri[kHotTri];
+    for (int j = threadIdx.x; j < kHotTri; j += blockDim.x) tri[j] = 0;
+    __syncthreads();
+    const int64_t n = n_docs * L;
+    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t b = int64_t(blockIdx.x) * per, e = std::min(n, b + per);
+    for (int64_t idx = b + threadIdx.x; idx < e; idx += 256) {
+        const int64_t d = idx / L, k = idx % L;
+        const int32_t *x = X + d * L;
+        const int32_t a = x[k];
+        if (a == -1) continue;
+        const int ha = hot_of[a];
+        const int64_t jd = last_start[d];
+        const int64_t l_end = std::min(L, k + w);
+        const int64_t hi = std::min(k, jd);
+        for (int64_t l = k; l < l_end; ++l) {
+            const int32_t bb = x[l];
+            if (bb == -1) break;                          // graphbuilder.pyx:106-111
+            const int64_t lo = std::max<int64_t>(0, l - w + 1);
+            if (hi < lo) continue;
+            const uint32_t c = static_cast<uint32_t>(hi - lo + 1);
+            const int hb = ha >= 0 ? hot_of[bb] : -1;
+            if (hb >= 0)
+                atomicAdd(&tri[sym_diag_idx(ha, hb, kHotWords)], c);
+            else
+                atomicAdd(&cij[sym_diag_idx(a, bb, V)], c);
+        }
+    }
+    __syncthreads();
+    // flush: packed index -> (row >= col) of the hot triangle -> the two words
+    for (int j = threadIdx.x; j < kHotTri; j += blockDim.x) {
+        const uint32_t c = tri[j];
+        if (c == 0) continue;
+        int col = 0, rem = j;
+        while (rem >= kHotWords - col) {                  // column `col` of the packed triangle holds kHotWords - col entries
+            rem -= kHotWords - col;
+            ++col;
+        }
+        const int row = col + rem;
+        atomicAdd(&cij[sym_diag_idx(hot_word[row], hot_word[col], V)], c);
     }
 }
 
@@ -205,9 +283,52 @@ int build(tgcn_wwedges &we, const int32_t *X, int64_t D, int64_t L, int64_t V, i
             X, D, L, w, static_cast<int32_t *>(last.p), static_cast<unsigned long long *>(nwin.p));
         TGCN_HIP_CHECK(hipGetLastError());
         const int64_t n = D * L;
-        k_pair_counts<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(
-            X, D, L, w, V, static_cast<int32_t *>(last.p), we.cij);
-        TGCN_HIP_CHECK(hipGetLastError());
+        static const bool privatise = [] {
+            const char *e = std::getenv("TGCN_WW_HOT_PAIRS");
+            return e ? std::atoi(e) != 0 : true;
+        }();
+        if (privatise && V > kHotWords && n >= (int64_t(1) << 16)) {
+            // token histogram (vocabulary ids in chunks that fit the LDS), top-H words on the host
+            Tmp hist, hot_of_d, hot_word_d;
+            TGCN_CHECK(hist.alloc(sizeof(uint32_t) * V));
+            TGCN_CHECK(hot_of_d.alloc(sizeof(int16_t) * V));
+            TGCN_CHECK(hot_word_d.alloc(sizeof(int32_t) * kHotWords));
+            TGCN_HIP_CHECK(hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * V, s));
+            for (int64_t v0 = 0; v0 < V; v0 += kHistChunk) {
+                const int64_t v1 = std::min<int64_t>(V, v0 + kHistChunk);
+                const size_t lds = sizeof(uint32_t) * static_cast<size_t>(v1 - v0);
+                TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_token_hist),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                k_token_hist<<<256, 1024, lds, s>>>(X, n, v0, v1, static_cast<uint32_t *>(hist.p));
+                TGCN_HIP_CHECK(hipGetLastError());
+            }
+            std::vector<uint32_t> h_hist(static_cast<size_t>(V));
+            TGCN_HIP_CHECK(hipMemcpyAsync(h_hist.data(), hist.p, sizeof(uint32_t) * V, hipMemcpyDeviceToHost, s));
+            TGCN_HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<int32_t> order(static_cast<size_t>(V));
+            for (int64_t v = 0; v < V; ++v) order[v] = static_cast<int32_t>(v);
+            std::partial_sort(order.begin(), order.begin() + kHotWords, order.end(), [&](int32_t x, int32_t y) {
+                return h_hist[x] != h_hist[y] ? h_hist[x] > h_hist[y] : x < y;
+            });
+            std::vector<int16_t> h_hot_of(static_cast<size_t>(V), int16_t(-1));
+            std::vector<int32_t> h_hot_word(kHotWords);
+            for (int k = 0; k < kHotWords; ++k) {
+                h_hot_word[k] = order[k];
+                h_hot_of[order[k]] = static_cast<int16_t>(k);
+            }
+            TGCN_HIP_CHECK(hipMemcpyAsync(hot_of_d.p, h_hot_of.data(), sizeof(int16_t) * V, hipMemcpyHostToDevice, s));
+            TGCN_HIP_CHECK(hipMemcpyAsync(hot_word_d.p, h_hot_word.data(), sizeof(int32_t) * kHotWords, hipMemcpyHostToDevice, s));
+            const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(2048, (n + 4095) / 4096));
+            k_pair_counts_hot<<<blocks, 256, 0, s>>>(X, D, L, w, V, static_cast<int32_t *>(last.p),
+                                                     static_cast<int16_t *>(hot_of_d.p),
+                                                     static_cast<int32_t *>(hot_word_d.p), we.cij);
+            TGCN_HIP_CHECK(hipGetLastError());
+            TGCN_HIP_CHECK(hipStreamSynchronize(s));      // the host vectors and Tmp buffers leave scope
+        } else {
+            k_pair_counts<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(
+                X, D, L, w, V, static_cast<int32_t *>(last.p), we.cij);
+            TGCN_HIP_CHECK(hipGetLastError());
+        }
     }
     unsigned long long h_nw = 0;
     TGCN_HIP_CHECK(hipMemcpyAsync(&h_nw, nwin.p, sizeof(h_nw), hipMemcpyDeviceToHost, s));

@@ -88,6 +88,28 @@ def test_gpu_builder_equals_oracle_bit_exact(cuda, V, D, L, win):
 
 
 @pytest.mark.gpu
+def test_gpu_builder_with_zipf_tokens_hot_pairs_counted_in_lds(cuda):
+    """A Zipf-distributed corpus large enough for the hot-pair path (k_pair_counts_hot: the pairs among the 128
+    most frequent words are counted in LDS and flushed once per workgroup): counts, edges and weights still
+    equal the CPU restatement bit for bit, including the diagonal entries every token adds to."""
+    from pytextgcn_amd.graphbuilder import compute_word_word_edges, sliding_window_tester
+    rng = np.random.default_rng(7)
+    V, D, L, win = 3000, 1500, 80, 20
+    p = 1.0 / np.arange(1, V + 1) ** 1.05
+    X = rng.permutation(V)[rng.choice(V, size=(D, L), p=p / p.sum())].astype(np.int32)   # hot words at scattered ids
+    lens = rng.integers(L // 2, L + 1, size=D)
+    for d in range(D):
+        X[d, lens[d]:] = -1
+    assert D * L >= 1 << 16 and V > 128                         # the conditions of the hot-pair path
+    c_ref, _ = G.sliding_window(X, V, win)
+    np.testing.assert_equal(sliding_window_tester(X, V, D, L, win), c_ref)
+    coo_ref, w_ref = G.compute_word_word_edges(X, V, win)
+    coo, w = compute_word_word_edges(X, V, D, L, win)
+    np.testing.assert_equal(coo, coo_ref)
+    np.testing.assert_equal(w, w_ref)
+
+
+@pytest.mark.gpu
 def test_gpu_builder_edge_cases_and_errors(cuda):
     from pytextgcn_amd.graphbuilder import compute_word_word_edges, sliding_window_tester
     X = np.full((4, 6), -1, dtype=np.int32)                     # only padding: windows but no counts
