@@ -237,7 +237,8 @@ def note_colsum(t: Tensor, sums: Tensor) -> None:
     """Record `sums == t.sum(0)` for the tensor `t` as it is now (any later in-place edit invalidates the note)."""
     import weakref
     key = t.data_ptr()
-    _KNOWN_COLSUMS[key] = (weakref.ref(t, lambda _, k=key: _KNOWN_COLSUMS.pop(k, None)), tuple(t.shape), t._version, sums)
+    _KNOWN_COLSUMS[key] = (weakref.ref(t, lambda _, k=key: _KNOWN_COLSUMS.pop(k, None)), tuple(t.shape), t._version, sums,
+                           sums._version)
 
 
 def _known_colsum(g: Tensor) -> Optional[Tensor]:
@@ -246,8 +247,8 @@ def _known_colsum(g: Tensor) -> Optional[Tensor]:
         return None
     t = hit[0]()
     if t is None or t.data_ptr() != g.data_ptr() or hit[1] != tuple(g.shape) or hit[2] != g._version \
-            or t._version != g._version or not g.is_contiguous():
-        return None
+            or t._version != g._version or not g.is_contiguous() or hit[3]._version != hit[4]:
+        return None                        # (the last test: somebody scaled or clipped the noted sums in place)
     return hit[3]
 
 

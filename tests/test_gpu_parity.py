@@ -550,7 +550,9 @@ def test_masked_cross_entropy_leaves_the_bias_gradient(cuda, n, C, scale):
     assert ((seen["colsum"].cpu().double() - want).abs().max() / want.abs().max()).item() < 2e-5
     # and against the gradient actually written (same numbers, another summation order)
     assert rel_err(seen["colsum"], seen["g"].double().sum(0).float()) < 2e-5
-    seen["g"].add_(1.0)                                           # an edit invalidates the note
+    seen["colsum"].mul_(2.0)                                      # sums edited in place (gradient clipping): stale too
+    assert plan_mod._known_colsum(seen["g"]) is None
+    seen["g"].add_(1.0)                                           # an edit of the matrix invalidates the note
     assert plan_mod._known_colsum(seen["g"]) is None
     assert rel_err(plan_mod.colsum(seen["g"]), seen["g"].double().sum(0).float()) < TOL
 
