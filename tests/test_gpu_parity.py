@@ -229,6 +229,28 @@ def test_results_are_bitwise_reproducible(cuda):
     a = plan.spmm(x)
     plan2 = GraphPlan(g.edge_index, g.edge_attr, 20000)
     assert torch.equal(a, plan.spmm(x)) and torch.equal(a, plan2.spmm(x))
+    # the reductions of the training step as well: every sum runs in a fixed order (no float atomics anywhere)
+    from pytextgcn_amd import dense
+    from pytextgcn_amd.functional import masked_cross_entropy
+    n, C = 150_000, 64
+    logits = torch.randn(n, C, device=cuda)
+    y = torch.randint(0, C, (n,), device=cuda)
+    mask = torch.rand(n, device=cuda) < 0.4
+    runs = []
+    for _ in range(2):
+        seen = {}
+        lg = logits.clone().requires_grad_()
+        probe = lg * 1.0
+        def hook(gr, seen=seen):
+            seen["db"] = colsum(gr).clone()                     # (returns None: the gradient passes unchanged)
+        probe.register_hook(hook)
+        loss = masked_cross_entropy(probe, y, mask)
+        loss.backward()
+        w = torch.randn(200, C, device=cuda, generator=torch.Generator(device=cuda).manual_seed(5))
+        dh = dense.gemm_nt(lg.grad, w, note_colsums=True)
+        runs.append((loss.detach().clone(), lg.grad.clone(), seen["db"], colsum(dh).clone(), colsum(x).clone()))
+    for u, v in zip(*runs):
+        assert torch.equal(u, v)
 
 
 def test_colsum(cuda):
