@@ -207,7 +207,7 @@ def hbm_activity(step_fn, dev, seconds=1.5):
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
-def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, fuse_w1=False):
+def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, fuse_w1=False, split_gemms=False):
     """One epoch as flat_amazon.py:99-117 defines it: train step (fwd, CE on train_mask, zero_grad,
     bwd, Adam(amsgrad) step) + eval forward + validation loss + metric transfer to the host.
     fused=False: the reference's loop body with its own operators (torch CrossEntropyLoss on
@@ -224,6 +224,8 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     pkg.enable_activation_reuse(reuse)
     pkg.enable_linear_collapse(collapse)
     pkg.enable_fused_dropout(fused)          # dropout fused into the next layer's GEMMs (tgcn_gemm_*_dropout)
+    from pytextgcn_amd import dense as _dense
+    _dense.enable_split_gemms(split_gemms)   # opt-in numerical mode of the layer-2 products (fp32-accurate, not bit-equal)
     model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
     Opt = pkg.optim.Adam if fused else torch.optim.Adam
     opt = Opt(model.parameters(), lr=0.05, amsgrad=True)
@@ -277,6 +279,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     pkg.enable_activation_reuse(False)
     pkg.enable_linear_collapse(False)
     pkg.enable_fused_dropout(False)
+    _dense.enable_split_gemms(False)
     return sorted(times)[len(times) // 2]
 
 
@@ -560,7 +563,7 @@ def main():
     # the step contains collectives every rank must enter)
     hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
 
-    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = None
+    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
@@ -574,6 +577,7 @@ def main():
         epoch_ms_collapse = epoch_time_ms(g, F, C, fused=True, collapse=True)
         epoch_ms_w1 = epoch_time_ms(g, F, C, fused=True, fuse_w1=True)
         epoch_ms_w1_reuse = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True)    # both switches are bitwise neutral
+        epoch_ms_split = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True)
 
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
@@ -648,6 +652,9 @@ def main():
             # every step of the epoch is still executed, bit for bit the same weights
             "epoch_ms_fused_w1_update_in_backward": epoch_ms_w1,
             "epoch_ms_fused_w1_update_in_backward_with_activation_reuse": epoch_ms_w1_reuse,
+            # the same with the layer-2 products in the opt-in split-bf16 mode (dense.enable_split_gemms: fp32-accurate,
+            # NOT bit-equal to the fp32 FMA chain -- reported apart for that reason)
+            "epoch_ms_fused_w1_reuse_split_bf16_gemms": epoch_ms_split,
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
             "exchange_selection": exchange_selection,

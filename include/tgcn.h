@@ -263,6 +263,14 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
 int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                          int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
                          size_t workspace_bytes, tgcn_stream stream);
+/* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt (+ _dropout, _colsum) for the two
+ * shapes of the GCN layers (nn: k = 200, n <= 64; nt: k = 64, 193 <= n <= 224).  on != 0: every fp32 product is
+ * formed from an exact three-way bf16 split of both operands on the bf16 matrix cores (six partial products,
+ * fp32 accumulation, dropped terms <= 2^-23 relative): fp32-accurate, NOT the fp32 FMA chain bit for bit, +-inf
+ * operands give nan.  Default off (TGCN_GEMM_SPLIT=1 in the environment turns it on at load).  Returns the
+ * previous setting. */
+int tgcn_set_gemm_split(int on);
+
 /* tgcn_gemm_nt_colsum -- tgcn_gemm_nt (seed == NULL) or tgcn_gemm_nt_dropout (seed != NULL) that also returns
  * colsum[j] = sum_r C[r, j], summed from the accumulator tiles as they are stored: with C = dH1 (the gradient of
  * the first layer's output) this is that layer's bias gradient (the autograd of `out += bias`, triggered at

@@ -7,9 +7,10 @@ layers as hand-written HIP kernels (libtgcn.so, include/tgcn.h) on an AMD Instin
 from . import functional, models, optim, train
 from .conv import GCNConv, enable_activation_reuse
 from .data import Data
+from .dense import enable_split_gemms
 from .models import GCN, enable_fused_dropout, enable_linear_collapse
 from .plan import GraphPlan, clear_plan_cache, colsum, plan_for
 from .text2graph import Text2GraphTransformer
 
 __all__ = ["Text2GraphTransformer", "models", "functional", "optim", "train", "GCN", "GCNConv", "Data", "GraphPlan", "plan_for", "colsum",
-           "clear_plan_cache", "enable_activation_reuse", "enable_linear_collapse", "enable_fused_dropout"]
+           "clear_plan_cache", "enable_activation_reuse", "enable_linear_collapse", "enable_fused_dropout", "enable_split_gemms"]

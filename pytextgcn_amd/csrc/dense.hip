@@ -16,6 +16,9 @@
 // of one row with ONE float4 per lane (lanes 0-31 take k = 8q..8q+3, lanes 32-63 k = 8q+4..8q+7) and
 // spend it over 4 MFMA steps; the matching rows of the small operand sit in LDS.
 #include <algorithm>
+#include <atomic>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -278,6 +281,185 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
 }
 
 // ---------------------------------------------------------------------------------------------
+// Opt-in (tgcn_set_gemm_split): the same tall products with every fp32 product formed from an EXACT three-way
+// bf16 split of both operands, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2: 8 + 8 + 8
+// significand bits, no bit lost), on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Of the nine partial
+// products the six down to 2^-16 are taken (a1b1; a1b2, a2b1; a1b3, a2b2, a3b1); the dropped ones are <= 2^-23
+// of |a||b|, the size of one fp32 rounding.  12 matrix-pipe cycles per unit of k instead of 32 (the fp32
+// MFMA), which takes the product off the matrix-pipe roof and onto the HBM one.  NOT the fp32 FMA chain bit for
+// bit; +-inf operands give nan (inf - inf in the split).  Built for the two shapes of the GCN layers only: the
+// 16-wide k groups are fully unrolled (NQ of them; k = 16 NQ or 16 NQ - 8) around a counted load ring.
+// Fragment maps (cdna_hip_programming.md section 3): lane l = (r = l & 31, h = l >> 5) holds A[row r][8h + j] and
+// B[8h + j][col r], j = 0..7; the accumulator layout is that of the fp32 32x32 tile, so the epilogue is shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 {
+    bf16x8 p1, p2, p3;
+};
+
+__device__ __forceinline__ Split3 split3(const f32x8 a) {
+    Split3 s;
+    s.p1 = __builtin_convertvector(a, bf16x8);                         // round to nearest even
+    const f32x8 r1 = a - __builtin_convertvector(s.p1, f32x8);         // exact
+    s.p2 = __builtin_convertvector(r1, bf16x8);
+    const f32x8 r2 = r1 - __builtin_convertvector(s.p2, f32x8);        // exact, <= 8 significant bits
+    s.p3 = __builtin_convertvector(r2, bf16x8);
+    return s;
+}
+
+template <int V>
+__device__ __forceinline__ void wait_vmcnt(f32x4 &lo, f32x4 &hi) {
+    // the two ring slots about to be read are in/out operands, so that no consumer is scheduled above the wait
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(V) : "memory");
+}
+
+constexpr int kSplitWaves = 8;
+
+template <class F, int... Q>
+__device__ __forceinline__ void unroll_steps(F &f, std::integer_sequence<int, Q...>) {
+    (f(std::integral_constant<int, Q>{}), ...);
+}
+
+// library-wide switch (tgcn_set_gemm_split; initial value from TGCN_GEMM_SPLIT)
+std::atomic<int> g_gemm_split{[] {
+    const char *e = std::getenv("TGCN_GEMM_SPLIT");
+    return e ? std::atoi(e) : 0;
+}()};
+
+template <int NT, bool TRANS_B, int NQ, bool DROP, bool COLSUM>
+__global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const float *__restrict__ A, int64_t lda,
+                                                                     const float *__restrict__ B, int64_t ldb,
+                                                                     float *__restrict__ C, int64_t ldc, int64_t N, int k,
+                                                                     int n, const Drop drop, float *__restrict__ colpart) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int npad = 32 * NT;
+    constexpr int per_part = NQ * 2 * npad;                 // fragments (8 x bf16) per split part: [q][h][col]
+    bf16x8 *img = reinterpret_cast<bf16x8 *>(lds_raw);
+    float csum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) csum[t] = 0.f;
+    uint32_t s_lo = 0, s_hi = 0;
+    if constexpr (DROP) {
+        const uint64_t sd = *drop.seed;
+        s_lo = uint32_t(sd);
+        s_hi = uint32_t(sd >> 32);
+    }
+    // stage the small operand: three bf16 images, zero padded, in fragment order
+    for (int f = threadIdx.x; f < per_part; f += blockDim.x) {
+        const int col = f % npad, hh = (f / npad) & 1, q = f / (2 * npad);
+        f32x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 16 * q + 8 * hh + j;
+            v[j] = (kk < k && col < n) ? (TRANS_B ? B[int64_t(col) * ldb + kk] : B[int64_t(kk) * ldb + col]) : 0.f;
+        }
+        const Split3 sp = split3(v);
+        img[f] = sp.p1;
+        img[per_part + f] = sp.p2;
+        img[2 * per_part + f] = sp.p3;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int64_t n_blocks = (N + 31) / 32;
+    // the last k group may hold 8 columns only (k = 16 NQ - 8): its upper half re-reads the lower one (a valid
+    // address of the same row; the matching rows of the B images are zero)
+    const bool last_half_valid = 16 * (NQ - 1) + 8 * half < k;
+    for (int64_t blk = int64_t(blockIdx.x) * kSplitWaves + wave; blk < n_blocks; blk += int64_t(gridDim.x) * kSplitWaves) {
+        const int64_t row = blk * 32 + r;
+        uint32_t a_key = 0;
+        if constexpr (DROP && !TRANS_B) a_key = drop_row_key(s_lo, s_hi, row);
+        const float *arow = A + std::min(row, N - 1) * lda;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        constexpr int RING = NQ < 8 ? NQ : 8;               // k groups in flight
+        f32x4 ring[2 * RING];
+        auto issue = [&](int slot, int q) {
+            const float *p = arow + 16 * q + ((q == NQ - 1 && !last_half_valid) ? 0 : 8 * half);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[2 * slot]) : "v"(p) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(ring[2 * slot + 1]) : "v"(p) : "memory");
+        };
+#pragma unroll
+        for (int q = 0; q < RING; ++q) issue(q, q);
+        auto step = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int slot = q % RING;
+            constexpr int later = (NQ - 1 - q) < (RING - 1) ? (NQ - 1 - q) : (RING - 1);   // k groups issued after this one
+            wait_vmcnt<2 * later>(ring[2 * slot], ring[2 * slot + 1]);
+            f32x8 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = ring[2 * slot][j];
+                a[4 + j] = ring[2 * slot + 1][j];
+            }
+            if constexpr (q + RING < NQ) issue(slot, q + RING);
+            if constexpr (DROP && !TRANS_B) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = drop_elem(a[j], a_key, drop_col_term(16 * q + 8 * half + j), drop);
+            }
+            const Split3 sa = split3(a);
+            const bf16x8 *bq = img + (q * 2 + half) * npad + r;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 b1 = bq[32 * t], b2 = bq[per_part + 32 * t], b3 = bq[2 * per_part + 32 * t];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p3, b1, acc[t], 0, 0, 0);   // smallest terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p2, b2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p1, b3, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p2, b1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p1, b2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa.p1, b1, acc[t], 0, 0, 0);
+            }
+        };
+        unroll_steps(step, std::make_integer_sequence<int, NQ>{});
+        // epilogue: C[(i&3) + 8*(i>>2) + 4*half][32 t + r], as in k_gemm_tall
+        uint32_t c_key[16];
+        if constexpr (DROP && TRANS_B) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = 32 * t + r;
+            if (col < n) {
+                const uint32_t cterm = drop_col_term(col);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    float out = acc[t][i];
+                    if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
+                    if (orow < N) {
+                        C[orow * ldc + col] = out;      // (non-temporal stores here: 0.62 -> 0.90 ms, the L2 no longer merges the row pieces)
+                        if constexpr (COLSUM) csum[t] += out;
+                    }
+                }
+            }
+            if constexpr (TRANS_B && (DROP || COLSUM)) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (COLSUM) {
+        __syncthreads();                                    // every wave is done with the B images
+        float *cl = reinterpret_cast<float *>(lds_raw);     // [kSplitWaves][npad]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float v = csum[t] + __shfl_xor(csum[t], 32, 64);
+            if (half == 0) cl[wave * npad + 32 * t + r] = v;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kSplitWaves; ++w) sum += cl[w * npad + j];
+            colpart[int64_t(blockIdx.x) * n + j] = sum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // partial[b][kpad][npad] = sum over this workgroup's rows of A[r, :]^T G[r, :]
 // Both operands are read straight from global memory in fragment order: for one MFMA step (2 rows)
 // lanes 0-31 / 32-63 read 32 consecutive floats of row 2s / 2s+1 (two coalesced 128-byte segments).
@@ -400,6 +582,126 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
     }
 }
 
+// The tn product with split-bf16 operands (see k_gemm_tall_split): the reduction index is the ROW, so a K step of
+// v_mfma_f32_32x32x16_bf16 is 16 rows: lane (c, h) holds rows 8h .. 8h+7 of its column of A (M operand) and of
+// G (N operand) -- 8 strided 4-byte loads per 32-wide tile, lanes 0-31 / 32-63 on 128 consecutive bytes of two
+// rows 8 apart -- splits them (both operands come from global memory) and issues 6 MFMAs per tile pair.
+// Same partial-tile layout as k_gemm_tn_partial; rows_per_wg must be a multiple of 16.
+template <int NT, bool DROP>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restrict__ A, int64_t lda,
+                                                          const float *__restrict__ G, int64_t ldg, int64_t N, int k,
+                                                          int n, int64_t rows_per_wg, float *__restrict__ partial,
+                                                          const Drop drop) {
+    uint32_t s_lo = 0, s_hi = 0;
+    if constexpr (DROP) {
+        const uint64_t sd = *drop.seed;
+        s_lo = uint32_t(sd);
+        s_hi = uint32_t(sd >> 32);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int mt = (k + 31) / 32;
+    constexpr int npad = 32 * NT;
+    const int mpad = 32 * mt;
+    const int64_t r_begin = int64_t(blockIdx.x) * rows_per_wg;
+    const int64_t r_end = std::min(N, r_begin + rows_per_wg);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+    const int m0 = wave, m1 = wave + 4;
+    // columns past k / n are clamped (they only feed rows / columns of the padded tile nobody reads)
+    const int ca0 = std::min(32 * m0 + c, k - 1), ca1 = std::min(32 * m1 + c, k - 1);
+    int cg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cg[t] = std::min(32 * t + c, n - 1);
+    const bool two = m1 < mt;                       // the last wave may own one tile only
+    struct Stage {
+        float a0[8], a1[8], g[NT][8];
+        int64_t row0;
+    };
+    auto load_stage = [&](Stage &st, int64_t row0) {
+        st.row0 = row0;
+        // rows of this lane: row0 + 8 half + j; past the end of the slice they shadow its last row and are zeroed below
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t rr = std::min(row0 + 8 * half + j, r_end - 1);
+            st.a0[j] = A[rr * lda + ca0];
+            st.a1[j] = A[rr * lda + ca1];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) st.g[t][j] = G[rr * ldg + cg[t]];
+        }
+    };
+    auto mfma_stage = [&](const Stage &st) {
+        const bool whole = st.row0 + 16 <= r_end;          // wave-uniform: every row of the stage exists
+        f32x8 x0, x1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t rr = st.row0 + 8 * half + j;
+            const bool in = whole || rr < r_end;
+            float v0 = in ? st.a0[j] : 0.f, v1 = in ? st.a1[j] : 0.f;
+            if constexpr (DROP) {
+                const uint32_t key = drop_row_key(s_lo, s_hi, rr);
+                v0 = drop_elem(v0, key, drop_col_term(ca0), drop);
+                v1 = drop_elem(v1, key, drop_col_term(ca1), drop);
+            }
+            x0[j] = v0;
+            x1[j] = v1;
+        }
+        const Split3 s0 = split3(x0), s1 = split3(x1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x8 y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (whole || st.row0 + 8 * half + j < r_end) ? st.g[t][j] : 0.f;
+            const Split3 sg = split3(y);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p3, sg.p1, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p2, sg.p2, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p1, sg.p3, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p2, sg.p1, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p1, sg.p2, acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p1, sg.p1, acc[0][t], 0, 0, 0);
+            if (two) {
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p3, sg.p1, acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p2, sg.p2, acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p1, sg.p3, acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p2, sg.p1, acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p1, sg.p2, acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.p1, sg.p1, acc[1][t], 0, 0, 0);
+            }
+        }
+    };
+    if (r_end > r_begin) {
+        const int64_t n_st = (r_end - r_begin + 15) / 16;
+        Stage sa, sb;
+        load_stage(sa, r_begin);
+        for (int64_t it = 0; it < n_st; it += 2) {
+            if (it + 1 < n_st) load_stage(sb, r_begin + 16 * (it + 1));
+            mfma_stage(sa);
+            if (it + 1 < n_st) {
+                if (it + 2 < n_st) load_stage(sa, r_begin + 16 * (it + 2));
+                mfma_stage(sb);
+            }
+        }
+    }
+    float *out = partial + int64_t(blockIdx.x) * mpad * npad;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mtile = m == 0 ? m0 : m1;
+        if (mtile >= mt) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int orow = 32 * mtile + (i & 3) + 8 * (i >> 2) + 4 * half;
+                out[orow * npad + 32 * t + c] = acc[m][t][i];
+            }
+    }
+}
+
 // C[kk][j] = sum_b partial[b][kk][j], in block order (deterministic); one thread per element,
 // 4-way split over b combined through LDS to shorten the serial chain.
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict__ partial, int nb,
@@ -485,6 +787,28 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         if constexpr (COLSUM) return launch_colsum_final(colpart, grid_used, n, colsum, s);
         return TGCN_OK;
     };
+    if (g_gemm_split.load(std::memory_order_relaxed) != 0 && lda % 4 == 0) {
+        // split-bf16 products for the two shapes of the GCN layers (everything else keeps the fp32 MFMA kernels)
+#define TGCN_SPLIT(NT, NQ_)                                                                                         \
+    do {                                                                                                            \
+        const size_t lb = size_t(3) * NQ_ * 2 * (32 * NT) * 16;                                                     \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall_split<NT, TRANS_B, NQ_, DROP, COLSUM>);        \
+        TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb))); \
+        const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({(n_blocks + kSplitWaves - 1) / kSplitWaves, int64_t(n_cu), int64_t(kTallMaxGrid)}))); \
+        grid_used = grid;                                                                                           \
+        k_gemm_tall_split<NT, TRANS_B, NQ_, DROP, COLSUM><<<grid, 64 * kSplitWaves, lb, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
+                                                                                            drop, colpart);         \
+    } while (0)
+        if (!TRANS_B && !COLSUM && k == 200 && nt == 2) {
+            TGCN_SPLIT(2, 13);
+            return finish();
+        }
+        if (TRANS_B && k == 64 && nt == 7) {
+            TGCN_SPLIT(7, 4);
+            return finish();
+        }
+#undef TGCN_SPLIT
+    }
     if (!TRANS_B && k == 200 && nt == 2) {
         TGCN_TALL_K(2, true, 25);
         return finish();
@@ -599,6 +923,8 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
     return gemm_nt_impl("tgcn_gemm_nt_dropout", A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
 }
 
+int tgcn_set_gemm_split(int on) { return tgcn::g_gemm_split.exchange(on != 0 ? 1 : 0); }
+
 size_t tgcn_gemm_nt_colsum_workspace_bytes(int n) {
     return n > 0 ? sizeof(float) * static_cast<size_t>(tgcn::kTallMaxGrid) * static_cast<size_t>(n) : 0;
 }
@@ -644,6 +970,17 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
     const int64_t rows_per_wg = ((N + nb - 1) / nb + 1) & ~int64_t(1);  // even: steps are row pairs
     const int nt = (n + 31) / 32, mt = (k + 31) / 32;
     float *partial = static_cast<float *>(workspace);
+    if (g_gemm_split.load(std::memory_order_relaxed) != 0 && k == 200 && nt == 2 && !drop) {
+        // split-bf16 products for the weight gradient of the GCN's second layer (16-row K steps).  Without the
+        // fused dropout only: with it both operands are split AND every element of A is hashed on the vector
+        // ALU, which then outweighs the 6 MFMAs per tile pair (0.87 against 0.84 ms for the fp32 MFMA kernel at c4).
+        const int64_t rpw = ((N + nb - 1) / nb + 15) & ~int64_t(15);
+        k_gemm_tn_split<2, false><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rpw, partial, Drop{});
+        TGCN_HIP_CHECK(hipGetLastError());
+        k_gemm_tn_reduce<<<(k * n + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mt, 32 * nt, k, n, C, ldc);
+        TGCN_HIP_CHECK(hipGetLastError());
+        return TGCN_OK;
+    }
 #define TGCN_TN(NT)                                                                                          \
     do {                                                                                                     \
         if (drop)                                                                                            \

@@ -13,6 +13,13 @@ from .plan import _stream_ptr
 _MAX = 256
 
 
+def enable_split_gemms(on: bool = True) -> bool:
+    """Opt-in numerical mode of the layer-2 products (`tgcn_set_gemm_split`): fp32 products formed from an exact
+    three-way bf16 split on the bf16 matrix cores -- fp32-accurate, faster, but not the fp32 FMA chain bit for bit.
+    Returns the previous setting."""
+    return bool(_lib.load().tgcn_set_gemm_split(1 if on else 0))
+
+
 def supported(x: Tensor, w: Tensor) -> bool:
     k, n = w.shape
     kpad, npad = (k + 7) & ~7, 32 * ((n + 31) // 32)

@@ -845,6 +845,77 @@ def test_nt_gemm_leaves_the_column_sums_of_its_result(cuda, N, k, n, p):
     assert plan_mod._known_colsum(plain) is None
 
 
+def test_split_bf16_products_are_fp32_accurate_and_opt_in(cuda):
+    """pytextgcn_amd.enable_split_gemms(): the layer-2 products at the GCN shapes (nn k = 200 n <= 64; nt k = 64
+    n = 200; tn k = 200 n = 64 without the fused dropout) with every fp32 product formed from an exact three-way
+    bf16 split on the bf16 matrix cores.  The error against float64 must be of the size of the fp32 FMA chain's
+    (not bf16's), products with an identity operand are exact, the dropout mask is the same one, the column sums
+    in the nt epilogue still match, and the mode is off unless asked for."""
+    from pytextgcn_amd import dense, plan as plan_mod
+    assert pkg.enable_split_gemms(True) is False                       # off by default; returns the previous setting
+    try:
+        gen = torch.Generator().manual_seed(9)
+        N, h, C = 70_001, 200, 64
+        H = torch.randn(N, h, generator=gen).to(cuda)
+        W = (torch.randn(h, C, generator=gen) * 0.1).to(cuda)
+        G = torch.randn(N, C, generator=gen).to(cuda)
+        Hd, Wd, Gd = H.double(), W.double(), G.double()
+
+        def err(got, ref):
+            return ((got.double() - ref).abs().max() / ref.abs().max()).item()
+        assert err(dense.gemm_nn(H, W), Hd @ Wd) < 2e-6
+        assert err(dense.gemm_nt(G, W), Gd @ Wd.t()) < 2e-6
+        assert err(dense.gemm_tn(H, G), Hd.t() @ Gd) < 2e-6
+        eye = torch.eye(h, device=cuda)
+        b = ((torch.arange(h * C, device=cuda, dtype=torch.float32).reshape(h, C) % 97) - 11 * torch.arange(C, device=cuda)) * 1.37
+        assert torch.equal(dense.gemm_nn(eye, b), b) and torch.equal(dense.gemm_tn(eye, b), b)
+        assert torch.equal(dense.gemm_nt(torch.eye(C, device=cuda), b), b.t().contiguous())
+        # the fused dropout draws the same mask in both modes (same seed): zero pattern of the masked products
+        seed = dense.new_seed(cuda)
+        split_nn, split_nt = dense.gemm_nn(H, W, 0.5, seed), dense.gemm_nt(G, W, 0.5, seed, note_colsums=True)
+        sums = plan_mod._known_colsum(split_nt)
+        assert sums is not None and err(sums, split_nt.double().sum(0)) < 2e-5
+        pkg.enable_split_gemms(False)
+        plain_nn, plain_nt = dense.gemm_nn(H, W, 0.5, seed), dense.gemm_nt(G, W, 0.5, seed)
+        assert torch.equal(plain_nt == 0, split_nt == 0)
+        assert err(split_nn, plain_nn.double()) < 2e-6 and err(split_nt, plain_nt.double()) < 2e-6
+        assert not torch.equal(split_nn, plain_nn)                     # another rounding pattern: that is why it is opt-in
+        # shapes outside the two specialised ones are untouched by the switch
+        pkg.enable_split_gemms(True)
+        a2, w2 = torch.randn(5000, 96, generator=gen).to(cuda), torch.randn(96, 40, generator=gen).to(cuda)
+        on = dense.gemm_nn(a2, w2)
+        pkg.enable_split_gemms(False)
+        assert torch.equal(on, dense.gemm_nn(a2, w2))
+        # the whole training step in this mode (hidden 200, 64 classes: all three specialised shapes) tracks the plain one
+        from pytextgcn_amd.functional import masked_cross_entropy
+        from pytextgcn_amd.optim import Adam
+        n, classes = 6000, 64
+        g = synth.word_doc_graph(n, 90000, seed=41, n_classes=classes)
+        gd = pkg.Data(**{kk: getattr(g, kk) for kk in g.keys}).to(cuda)
+        torch.manual_seed(2)
+        base = pkg.GCN(n, classes, n_hidden_gcn=200, dropout=0.0)
+        traces = []
+        for mode in (False, True):
+            pkg.enable_split_gemms(mode)
+            m = pkg.GCN(n, classes, n_hidden_gcn=200, dropout=0.0)
+            m.load_state_dict(base.state_dict())
+            m = m.to(cuda).float()
+            o = Adam(m.parameters(), lr=0.02, amsgrad=True)
+            tr = []
+            for _ in range(4):
+                loss = masked_cross_entropy(m(gd), gd.y, gd.train_mask)
+                o.zero_grad(set_to_none=True)
+                loss.backward()
+                o.step()
+                tr.append(loss.item())
+            traces.append((tr, m.layers[1].weight.detach().clone()))
+        for x, y in zip(*[t[0] for t in traces]):
+            assert abs(x - y) < 1e-5 * abs(x)
+        assert rel_err(traces[1][1], traces[0][1]) < 1e-4              # four Adam steps amplify last-bit differences
+    finally:
+        pkg.enable_split_gemms(False)
+
+
 def test_dense_layer_autograd_uses_the_mfma_kernels(cuda):
     from pytextgcn_amd import dense
     gen = torch.Generator().manual_seed(5)

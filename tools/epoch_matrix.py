@@ -21,3 +21,8 @@ for round_ in range(2):
         for w1 in (False, True):
             ms = bench.epoch_time_ms(g, F, C, fused=True, reps=reps, reuse=reuse, fuse_w1=w1)
             print(json.dumps({"round": round_, "activation_reuse": reuse, "w1_update_in_backward": w1, "epoch_ms": round(ms, 3)}), flush=True)
+    # + the opt-in split-bf16 mode of the layer-2 products (not bitwise neutral: fp32-accurate)
+    for reuse, w1 in ((False, False), (True, True)):
+        ms = bench.epoch_time_ms(g, F, C, fused=True, reps=reps, reuse=reuse, fuse_w1=w1, split_gemms=True)
+        print(json.dumps({"round": round_, "activation_reuse": reuse, "w1_update_in_backward": w1, "split_bf16_gemms": True,
+                          "epoch_ms": round(ms, 3)}), flush=True)
