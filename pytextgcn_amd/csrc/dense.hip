@@ -331,11 +331,16 @@ template <int NT, bool TRANS_B, int NQ, bool DROP, bool COLSUM>
 __global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const float *__restrict__ A, int64_t lda,
                                                                      const float *__restrict__ B, int64_t ldb,
                                                                      float *__restrict__ C, int64_t ldc, int64_t N, int k,
-                                                                     int n, const Drop drop, float *__restrict__ colpart) {
+                                                                     int n, const Drop drop, float *__restrict__ colpart,
+                                                                     const bool row_stores) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int npad = 32 * NT;
     constexpr int per_part = NQ * 2 * npad;                 // fragments (8 x bf16) per split part: [q][h][col]
     bf16x8 *img = reinterpret_cast<bf16x8 *>(lds_raw);
+    // row_stores (contiguous C, n % 4 == 0): the result leaves through a per-wave LDS slice of 8 rows, as 16-byte
+    // stores over whole rows -- the 32 rows of a block are one contiguous run of C -- instead of 4-byte stores of
+    // 128-byte row pieces that straddle cache lines (rows of 800 bytes)
+    float *stage = reinterpret_cast<float *>(lds_raw + size_t(3) * per_part * 16) + (threadIdx.x >> 6) * (8 * npad);
     float csum[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) csum[t] = 0.f;
@@ -422,6 +427,33 @@ __global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const floa
             for (int i = 0; i < 16; ++i)
                 c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
         }
+        if (row_stores) {
+            const int64_t rows_here = std::min<int64_t>(32, N - blk * 32);
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {                 // rows 8 g8 .. 8 g8 + 7 of the block: registers 4 g8 .. 4 g8 + 3
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = 32 * t + r;
+                    const uint32_t cterm = drop_col_term(col);
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int i = 4 * g8 + i4;
+                        float out = acc[t][i];
+                        if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
+                        if (col < n) {
+                            stage[(i4 + 4 * half) * n + col] = out;
+                            if constexpr (COLSUM)
+                                if (8 * g8 + i4 + 4 * half < rows_here) csum[t] += out;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();             // the slice belongs to this wave: its LDS operations run in order
+                const int64_t live = std::min<int64_t>(8, rows_here - 8 * g8) * n / 4;      // float4s of existing rows
+                float4 *dst = reinterpret_cast<float4 *>(C + (blk * 32 + 8 * g8) * ldc);
+                for (int f = lane; f < live; f += 64) dst[f] = reinterpret_cast<const float4 *>(stage)[f];
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = 32 * t + r;
@@ -439,6 +471,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const floa
                 }
             }
             if constexpr (TRANS_B && (DROP || COLSUM)) __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
     if constexpr (COLSUM) {
@@ -791,13 +824,14 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         // split-bf16 products for the two shapes of the GCN layers (everything else keeps the fp32 MFMA kernels)
 #define TGCN_SPLIT(NT, NQ_)                                                                                         \
     do {                                                                                                            \
-        const size_t lb = size_t(3) * NQ_ * 2 * (32 * NT) * 16;                                                     \
+        const bool rs = TRANS_B && ldc == n && n % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0;              \
+        const size_t lb = size_t(3) * NQ_ * 2 * (32 * NT) * 16 + (rs ? size_t(kSplitWaves) * 8 * (32 * NT) * 4 : 0); \
         const void *fn = reinterpret_cast<const void *>(&k_gemm_tall_split<NT, TRANS_B, NQ_, DROP, COLSUM>);        \
         TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb))); \
         const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({(n_blocks + kSplitWaves - 1) / kSplitWaves, int64_t(n_cu), int64_t(kTallMaxGrid)}))); \
         grid_used = grid;                                                                                           \
         k_gemm_tall_split<NT, TRANS_B, NQ_, DROP, COLSUM><<<grid, 64 * kSplitWaves, lb, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
-                                                                                            drop, colpart);         \
+                                                                                            drop, colpart, rs);     \
     } while (0)
         if (!TRANS_B && !COLSUM && k == 200 && nt == 2) {
             TGCN_SPLIT(2, 13);
