@@ -17,6 +17,7 @@ run narrow_old TGCN_SPMM_NARROW_BUF=0
 run no_hot TGCN_HOT_ROWS=0
 run no_narrow TGCN_SPMM_NARROW=0
 run plain_loads TGCN_SPMM_VARIANT=8:0
+run gemm_split TGCN_GEMM_SPLIT=1
 run ce_kpl4 TGCN_CE_KPL=4
 run no_row_sort TGCN_ROW_SORT=0
 run big_items TGCN_ITEM_WEIGHT=2048 TGCN_MIN_PIECE=128 TGCN_COL_BLOCK=0
