@@ -788,10 +788,18 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
     // leave most CUs idle at the end)
     int n_cu = 256;
     {
+        // hipGetDeviceProperties fills a large struct (tens of microseconds): asked once per device
+        static std::atomic<int> cached[64] = {};
         int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            int v = cached[dev].load(std::memory_order_relaxed);
+            if (v == 0) {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+                if (v > 0) cached[dev].store(v, std::memory_order_relaxed);
+            }
+            if (v > 0) n_cu = v;
+        }
     }
 #define TGCN_TALL_K(NT, K8, NQ_)                                                                     \
     do {                                                                                          \
