@@ -483,6 +483,58 @@ def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref):
     assert bool(((v - vr).abs() <= 1e-3 * vr.abs() + 1e-30).all())
 
 
+def test_config_c4_dense_and_loss_kernels_at_full_size(cuda):
+    """The rest of the training step at BASELINE.json's c4 size (2 M rows, hidden 200, 64 classes): the three
+    layer-2 products (plain and with the fused dropout), the column sums, the fused cross-entropy with its
+    gradient / bias gradient / predictions -- against float64 arithmetic on the same device (torch, float64: an
+    independent implementation), over ALL rows."""
+    from pytextgcn_amd import dense
+    from pytextgcn_amd.functional import masked_cross_entropy
+    N, h, C = 2_000_000, 200, 64
+    gen = torch.Generator(device=cuda).manual_seed(44)
+    H = torch.randn(N, h, device=cuda, generator=gen)
+    W = torch.randn(h, C, device=cuda, generator=gen) * 0.1
+    G = torch.randn(N, C, device=cuda, generator=gen)
+    Wd = W.double()
+    xw = dense.gemm_nn(H, W)
+    assert rel_err(xw, H.double() @ Wd) < TOL
+    dh = dense.gemm_nt(G, W, note_colsums=True)
+    ref = G.double() @ Wd.t()
+    assert rel_err(dh, ref) < TOL
+    assert ((colsum(dh).double() - ref.sum(0)).abs().max() / ref.sum(0).abs().max()).item() < 2e-5
+    del ref
+    assert rel_err(dense.gemm_tn(H, G), H.double().t() @ G.double()) < TOL
+    # fused dropout: one mask in all three products; the masked operand reconstructed from the nt result's zero pattern
+    seed = dense.new_seed(cuda)
+    p = 0.5
+    keep = dense.gemm_nt(torch.ones(N, 1, device=cuda), torch.ones(h, 1, device=cuda), p, seed) != 0     # [N, h] keep mask
+    assert abs(keep.float().mean().item() - (1 - p)) < 2e-3
+    Hm = (H * keep).double() / (1 - p)
+    assert rel_err(dense.gemm_nn(H, W, p, seed), Hm @ Wd) < TOL
+    assert rel_err(dense.gemm_tn(H, G, p, seed), Hm.t() @ G.double()) < TOL
+    del Hm, keep
+    # loss, gradient, bias gradient, predictions
+    y = torch.randint(0, C, (N,), device=cuda, generator=gen)
+    mask = torch.rand(N, device=cuda, generator=gen) < 0.6
+    lg = (xw * 3).requires_grad_()
+    seen = {}
+
+    def hook(gr):
+        seen["db"] = colsum(gr).clone()
+    probe = lg * 1.0
+    probe.register_hook(hook)
+    loss, pred = masked_cross_entropy(probe, y, mask, return_pred=True)
+    loss.backward()
+    ref_lg = (xw * 3).double().requires_grad_()
+    ref_loss = torch.nn.functional.cross_entropy(ref_lg[mask], y[mask])
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < TOL * abs(ref_loss.item())
+    assert rel_err(lg.grad, ref_lg.grad) < TOL
+    want = ref_lg.grad.sum(0)
+    assert ((seen["db"].double() - want).abs().max() / want.abs().max()).item() < 2e-5
+    assert torch.equal(pred, (xw * 3).argmax(1))
+
+
 def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
     """The c4 plan (50 M edges) against the oracle's OWN normalisation, not against itself: rowptr / col
     bit-exact, values to 2e-6; then rows [0, 60 000) of M @ X (all word rows up to 1.3 M non-zeros each,
