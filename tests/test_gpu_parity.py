@@ -535,6 +535,30 @@ def test_config_c4_dense_and_loss_kernels_at_full_size(cuda):
     assert torch.equal(pred, (xw * 3).argmax(1))
 
 
+def test_config_c4_w1_update_in_the_backward_spmm_is_bitwise_at_full_size(cuda):
+    """tgcn_spmm_adam at the c4 size (W1 = 2 M x 200, every epilogue: row blocks, long-row segments, the dense hot
+    block): two steps of Adam(amsgrad) applied inside the transposed SpMM leave the parameter and all three state
+    tensors bit for bit where `tgcn_spmm` + `tgcn_adam_step` leave them."""
+    from pytextgcn_amd.optim import Adam
+    N, E, F = 2_000_000, 50_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    wa = torch.nn.Parameter(torch.randn(N, F, device=cuda, generator=gen) * 0.05)
+    wb = torch.nn.Parameter(wa.detach().clone())
+    oa, ob = Adam([wa], lr=0.05, amsgrad=True), Adam([wb], lr=0.05, amsgrad=True)
+    for step in range(2):
+        dh = torch.randn(N, F, device=cuda, generator=gen)
+        wa.grad = plan.spmm(dh, transpose=True)
+        oa.step()
+        wa.grad = None
+        assert ob._fused_update(wb, plan, dh)
+        assert torch.equal(wa, wb), step
+    for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+        assert torch.equal(oa.state[wa][k], ob.state[wb][k]), k
+    assert oa.state[wa]["step"] == ob.state[wb]["step"] == 2
+
+
 def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
     """The c4 plan (50 M edges) against the oracle's OWN normalisation, not against itself: rowptr / col
     bit-exact, values to 2e-6; then rows [0, 60 000) of M @ X (all word rows up to 1.3 M non-zeros each,
