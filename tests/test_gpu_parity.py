@@ -582,6 +582,24 @@ def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
     # the transposed path reuses the same block (M is bitwise symmetric): same rows, same oracle
     out_t = plan.spmm(x, None, transpose=True)[:R].cpu()
     assert rel_err(out_t, ref - b.cpu()) < TOL
+    del x, out, out_t, ref
+    # the whole eval forward at this size -- GCN(N -> 200 -> 64) on one-hot features, models.py:17-25 -- against the
+    # oracle's CSR end to end (C CSR SpMM with float64 accumulation, float64 X @ W2), over ALL 2 M rows
+    C = 64
+    torch.manual_seed(7)
+    model = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.5).to(cuda).float().eval()
+    with torch.no_grad():
+        model.layers[0].bias.normal_(0, 0.1)                      # zero biases (the init) would hide a bias bug
+        model.layers[1].bias.normal_(0, 0.1)
+        ar = torch.arange(N, device=cuda)
+        eye = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=cuda), (N, N)).coalesce()
+        logits = model(pkg.Data(x=eye, edge_index=g.edge_index, edge_attr=g.edge_attr)).cpu()
+        w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
+                                                     model.layers[1].weight, model.layers[1].bias))
+    h1 = csr_oracle.csr_spmm(rp_ref, col_ref, val_ref, w1, b1, acc64=True)
+    xw2 = (h1.double() @ w2.double()).float()
+    want = csr_oracle.csr_spmm(rp_ref, col_ref, val_ref, xw2, b2, acc64=True)
+    assert rel_err(logits, want) < TOL
 
 
 # ------------------------------------------------------------------------------------------------
