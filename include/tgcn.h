@@ -17,7 +17,10 @@
  *     synchronises `stream` (it is a one-off per graph).
  *   - a plan is immutable after creation: safe to share between threads and streams as long as
  *     concurrent calls use distinct workspaces.
- *   - all arithmetic is IEEE fp32; results are bitwise reproducible run to run (no atomics).
+ *   - all arithmetic is IEEE fp32; results are bitwise reproducible run to run (no floating-point atomics;
+ *     the word-word graph builder uses integer atomics, whose sums do not depend on the order).  The one
+ *     exception is opt-in: tgcn_set_gemm_split(1) forms the products of three dense kernels from exact bf16
+ *     splits of their fp32 operands (fp32-accurate and still reproducible, but not the fp32 FMA chain).
  */
 #ifndef TGCN_H_
 #define TGCN_H_
