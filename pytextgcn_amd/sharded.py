@@ -197,6 +197,7 @@ class ShardedGraph:
         self.hp, self.rp, self.n_local = part.hp, part.rp, part.n_local
         self.owned = part.owned(self.rank)
         self.real = self.owned >= 0
+        self._all_real = None                                 # resolved at the first bias gradient (colsum_real)
         # Normalisation over the WHOLE edge list (two vectors of N floats), then every rank cuts its own
         # two operators out of the edge list chunk by chunk: no rank ever holds the whole-graph plan, its
         # CSR or anything else of size nnz beyond the edge list it was handed.
@@ -443,6 +444,12 @@ class ShardedGraph:
     def colsum_real(self, g_local: Tensor) -> Tensor:
         """Column sums over this rank's real rows (padding rows carry zero gradient by
         construction, but are masked anyway)."""
+        if self._all_real is None:
+            self._all_real = bool(self.real.all().item())          # static: one synchronisation per graph
+        if self._all_real:
+            # no padding rows on this rank: the matrix as it is -- which lets the HIP engine hand back the sums its
+            # producer kernel left (plan.note_colsum: cross-entropy backward, nt GEMM epilogue) without reading it
+            return self.engine.colsum(g_local)
         return self.engine.colsum(g_local * self.real.unsqueeze(1).to(g_local.dtype))
 
     def allreduce_(self, tensors: List[Tensor]) -> None:
