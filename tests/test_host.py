@@ -167,6 +167,52 @@ def test_committed_round2_bench_line_carries_a_believable_roofline():
     assert d["epoch_ms_fused"] < d["epoch_ms"]
 
 
+def test_fused_dropout_hash_has_no_measurable_structure():
+    """The keep decision of the fused dropout is a stateless hash of (seed, row, col) (csrc/dense.hip: drop_row_key,
+    drop_col_term, drop_elem), restated here in numpy: keep rate, per-column rates and the correlation between
+    adjacent columns, columns two apart and adjacent rows stay within 4 sigma over 4 M elements, for three seeds and
+    three rates.  (A one-multiply finaliser fails this at columns two apart, z = +5 ... +6: DESIGN.md 4.5.)  The
+    GPU side reads the real mask back in test_fused_dropout_gemms_share_one_mask."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def u32(x):
+        return x & m32
+
+    def row_key(s_lo, s_hi, row):
+        h = u32(row ^ np.uint64(s_lo))
+        h = u32(h * np.uint64(0xCC9E2D51))
+        h = u32((h << np.uint64(15)) | (h >> np.uint64(17)))
+        h = u32(h * np.uint64(0x1B873593))
+        h = h ^ u32((row >> np.uint64(32)) + np.uint64(s_hi))
+        h = h ^ (h >> np.uint64(16))
+        return u32(h * np.uint64(0x85EBCA6B))
+
+    def elem(key, col):
+        h = u32(key + u32(col * np.uint64(0x9E3779B1)))
+        h = h ^ (h >> np.uint64(15))
+        h = u32(h * np.uint64(0x2C1B3C6D))
+        h = h ^ (h >> np.uint64(12))
+        h = u32(h * np.uint64(0x297A2D39))
+        return h ^ (h >> np.uint64(15))
+
+    rows = np.arange(20000, dtype=np.uint64)[:, None]
+    cols = np.arange(200, dtype=np.uint64)[None, :]
+    worst = 0.0
+    for seed in (0x0123456789ABCDEF, 1, 2 ** 63 + 12345):
+        h = elem(row_key(seed & 0xFFFFFFFF, seed >> 32, rows), cols)
+        for p in (0.5, 0.7, 0.1):
+            keep = (h >= np.uint64(int(p * 2 ** 32))).astype(np.float64)
+            q = 1.0 - p
+            var = q * (1.0 - q)
+            z = [(keep.mean() - q) / np.sqrt(var / keep.size)]
+            for a, b in ((keep[:, 1:], keep[:, :-1]), (keep[:, 2:], keep[:, :-2]), (keep[1:], keep[:-1])):
+                z.append(((a - q) * (b - q)).mean() / var * np.sqrt(a.size))
+            z.append(np.abs((keep.mean(0) - q) / np.sqrt(var / keep.shape[0])).max() - 1.0)   # max over 200 columns: ~3 expected
+            worst = max(worst, max(abs(v) for v in z))
+    assert worst < 4.0, worst
+
+
 def test_mask_count_cache_is_keyed_by_object_not_by_address():
     """A dead temporary's storage (and id) can be handed to the next mask: the cached row count must not
     follow it."""
