@@ -1638,6 +1638,38 @@ def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
     assert float(dense.gemm_nn(x, w, 1.0, seed).abs().max()) == 0.0
 
 
+def test_fused_dropout_mask_is_the_documented_hash(cuda):
+    """The mask the kernels draw equals the numpy restatement of the hash that tests/test_host.py checks
+    statistically (same seed, every element): the two tests pin the same function."""
+    import numpy as np
+    from pytextgcn_amd import dense
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def u32(x):
+        return x & m32
+    N, w, p = 1031, 200, 0.3
+    seed = dense.new_seed(cuda)
+    sd = int(seed.item()) & 0xFFFFFFFFFFFFFFFF
+    keep_gpu = (dense.gemm_nt(torch.ones(N, 1, device=cuda), torch.ones(w, 1, device=cuda), p, seed) != 0).cpu().numpy()
+    rows = np.arange(N, dtype=np.uint64)[:, None]
+    cols = np.arange(w, dtype=np.uint64)[None, :]
+    h = u32(rows ^ np.uint64(sd & 0xFFFFFFFF))
+    h = u32(h * np.uint64(0xCC9E2D51))
+    h = u32((h << np.uint64(15)) | (h >> np.uint64(17)))
+    h = u32(h * np.uint64(0x1B873593))
+    h = h ^ u32((rows >> np.uint64(32)) + np.uint64(sd >> 32))
+    h = h ^ (h >> np.uint64(16))
+    key = u32(h * np.uint64(0x85EBCA6B))
+    h = u32(key + u32(cols * np.uint64(0x9E3779B1)))
+    h = h ^ (h >> np.uint64(15))
+    h = u32(h * np.uint64(0x2C1B3C6D))
+    h = h ^ (h >> np.uint64(12))
+    h = u32(h * np.uint64(0x297A2D39))
+    h = h ^ (h >> np.uint64(15))
+    keep_np = h >= np.uint64(min(int(p * 4294967296.0), 4294967295))
+    assert (keep_gpu == keep_np).all()
+
+
 def test_gcn_with_fused_dropout(cuda):
     """pytextgcn_amd.enable_fused_dropout(): training forward/backward of the 2-layer GCN equal the oracle's with the
     SAME mask applied explicitly between the layers; eval mode and dropout = 0 are untouched; a fresh
