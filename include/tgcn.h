@@ -266,8 +266,9 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
 int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                          int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
                          size_t workspace_bytes, tgcn_stream stream);
-/* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt (+ _dropout, _colsum) for the two
- * shapes of the GCN layers (nn: k = 200, n <= 64; nt: k = 64, 193 <= n <= 224).  on != 0: every fp32 product is
+/* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt / _tn for the
+ * shapes of the GCN layers (nn: k = 200, n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64, contiguous
+ * operands; + the _dropout / _colsum forms).  on != 0: every fp32 product is
  * formed from an exact three-way bf16 split of both operands on the bf16 matrix cores (six partial products,
  * fp32 accumulation, dropped terms <= 2^-23 relative): fp32-accurate, NOT the fp32 FMA chain bit for bit, +-inf
  * operands give nan.  Default off (TGCN_GEMM_SPLIT=1 in the environment turns it on at load).  Returns the

@@ -616,15 +616,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
 }
 
 // The tn product with split-bf16 operands (see k_gemm_tall_split): the reduction index is the ROW, so a K step of
-// v_mfma_f32_32x32x16_bf16 is 16 rows: lane (c, h) holds rows 8h .. 8h+7 of its column of A (M operand) and of
-// G (N operand) -- 8 strided 4-byte loads per 32-wide tile, lanes 0-31 / 32-63 on 128 consecutive bytes of two
-// rows 8 apart -- splits them (both operands come from global memory) and issues 6 MFMAs per tile pair.
-// Same partial-tile layout as k_gemm_tn_partial; rows_per_wg must be a multiple of 16.
+// v_mfma_f32_32x32x16_bf16 is 16 rows.  A stage = 32 rows (two K steps) of A (contiguous: 32 k floats) and of G,
+// copied by the whole workgroup with 16-byte loads into a double-buffered LDS image (row pitch k + 4 / n + 4: the
+// two lane halves, 8 rows apart, then sit 32 banks apart); lane (c, h) reads rows 8h .. 8h+7 of its column of A
+// (M operand, two 32-wide tiles per wave) and of G (N operand) from there, masks (fused dropout), splits and issues
+// 6 MFMAs per tile pair.  (The first version read the fragments straight from global memory with 4-byte loads of
+// 128-byte row pieces: 0.67 ms at c4 where the 2.1 GB stream allows 0.43.)  Rows past the end of the workgroup's
+// slice are zero-filled in the copy.  Same partial-tile layout as k_gemm_tn_partial; contiguous operands
+// (lda == k, ldg == n, both multiples of 4), rows_per_wg a multiple of 16.
 template <int NT, bool DROP>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restrict__ A, int64_t lda,
-                                                          const float *__restrict__ G, int64_t ldg, int64_t N, int k,
-                                                          int n, int64_t rows_per_wg, float *__restrict__ partial,
-                                                          const Drop drop) {
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restrict__ A, const float *__restrict__ G,
+                                                          int64_t N, int k, int n, int64_t rows_per_wg,
+                                                          float *__restrict__ partial, const Drop drop) {
+    extern __shared__ __align__(16) float tn_lds[];
     uint32_t s_lo = 0, s_hi = 0;
     if constexpr (DROP) {
         const uint64_t sd = *drop.seed;
@@ -636,6 +640,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
     const int mt = (k + 31) / 32;
     constexpr int npad = 32 * NT;
     const int mpad = 32 * mt;
+    const int kp = k + 4, np_ = n + 4;                       // LDS row pitches
+    constexpr int SR = 32;                                   // rows per stage: two K steps of 16 between workgroup barriers
+    const int stage_floats = SR * kp + SR * np_;
     const int64_t r_begin = int64_t(blockIdx.x) * rows_per_wg;
     const int64_t r_end = std::min(N, r_begin + rows_per_wg);
     f32x16 acc[2][NT];
@@ -646,38 +653,52 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
     const int m0 = wave, m1 = wave + 4;
+    const bool two = m1 < mt;                                // the last wave may own one tile only
     // columns past k / n are clamped (they only feed rows / columns of the padded tile nobody reads)
     const int ca0 = std::min(32 * m0 + c, k - 1), ca1 = std::min(32 * m1 + c, k - 1);
     int cg[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) cg[t] = std::min(32 * t + c, n - 1);
-    const bool two = m1 < mt;                       // the last wave may own one tile only
-    struct Stage {
-        float a0[8], a1[8], g[NT][8];
-        int64_t row0;
-    };
-    auto load_stage = [&](Stage &st, int64_t row0) {
-        st.row0 = row0;
-        // rows of this lane: row0 + 8 half + j; past the end of the slice they shadow its last row and are zeroed below
+    const int a_vec = SR * k / 4, g_vec = SR * n / 4;        // float4s of one stage
+    constexpr int AV = 8, GV = 4;                            // float4s per thread and stage (k <= 256, n <= 128)
+    float4 ra[AV], rg[GV];
+    auto fetch = [&](int64_t row0) {                          // global -> registers (zeros past the slice)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t rr = std::min(row0 + 8 * half + j, r_end - 1);
-            st.a0[j] = A[rr * lda + ca0];
-            st.a1[j] = A[rr * lda + ca1];
+        for (int u = 0; u < AV; ++u) {
+            const int f = threadIdx.x + 256 * u;
+            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < a_vec && row0 + f / (k / 4) < r_end) ra[u] = reinterpret_cast<const float4 *>(A + row0 * k)[f];
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) st.g[t][j] = G[rr * ldg + cg[t]];
+        for (int u = 0; u < GV; ++u) {
+            const int f = threadIdx.x + 256 * u;
+            rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < g_vec && row0 + f / (n / 4) < r_end) rg[u] = reinterpret_cast<const float4 *>(G + row0 * n)[f];
         }
     };
-    auto mfma_stage = [&](const Stage &st) {
-        const bool whole = st.row0 + 16 <= r_end;          // wave-uniform: every row of the stage exists
+    auto deposit = [&](int buf) {                             // registers -> LDS image `buf`
+        float *la = tn_lds + buf * stage_floats, *lg = la + SR * kp;
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            const int f = threadIdx.x + 256 * u;
+            if (f < a_vec) *reinterpret_cast<float4 *>(la + (f / (k / 4)) * kp + 4 * (f % (k / 4))) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GV; ++u) {
+            const int f = threadIdx.x + 256 * u;
+            if (f < g_vec) *reinterpret_cast<float4 *>(lg + (f / (n / 4)) * np_ + 4 * (f % (n / 4))) = rg[u];
+        }
+    };
+    auto compute = [&](int buf, int64_t row0, int ks) {      // K step ks (0 / 1) of the stage: its rows 16 ks .. 16 ks + 15
+        const float *la = tn_lds + buf * stage_floats + (16 * ks + 8 * half) * kp;
+        const float *lg = tn_lds + buf * stage_floats + SR * kp + (16 * ks + 8 * half) * np_;
+        row0 += 16 * ks;
         f32x8 x0, x1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t rr = st.row0 + 8 * half + j;
-            const bool in = whole || rr < r_end;
-            float v0 = in ? st.a0[j] : 0.f, v1 = in ? st.a1[j] : 0.f;
+            float v0 = la[j * kp + ca0], v1 = la[j * kp + ca1];
             if constexpr (DROP) {
-                const uint32_t key = drop_row_key(s_lo, s_hi, rr);
+                const uint32_t key = drop_row_key(s_lo, s_hi, row0 + 8 * half + j);
                 v0 = drop_elem(v0, key, drop_col_term(ca0), drop);
                 v1 = drop_elem(v1, key, drop_col_term(ca1), drop);
             }
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
         for (int t = 0; t < NT; ++t) {
             f32x8 y;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = (whole || st.row0 + 8 * half + j < r_end) ? st.g[t][j] : 0.f;
+            for (int j = 0; j < 8; ++j) y[j] = lg[j * np_ + cg[t]];
             const Split3 sg = split3(y);
             acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p3, sg.p1, acc[0][t], 0, 0, 0);
             acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.p2, sg.p2, acc[0][t], 0, 0, 0);
@@ -708,16 +729,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
         }
     };
     if (r_end > r_begin) {
-        const int64_t n_st = (r_end - r_begin + 15) / 16;
-        Stage sa, sb;
-        load_stage(sa, r_begin);
-        for (int64_t it = 0; it < n_st; it += 2) {
-            if (it + 1 < n_st) load_stage(sb, r_begin + 16 * (it + 1));
-            mfma_stage(sa);
-            if (it + 1 < n_st) {
-                if (it + 2 < n_st) load_stage(sa, r_begin + 16 * (it + 2));
-                mfma_stage(sb);
-            }
+        const int64_t n_st = (r_end - r_begin + SR - 1) / SR;
+        fetch(r_begin);
+        deposit(0);
+        __syncthreads();
+        for (int64_t it = 0; it < n_st; ++it) {
+            if (it + 1 < n_st) fetch(r_begin + SR * (it + 1));      // in flight under the MFMAs of this stage
+            compute(int(it & 1), r_begin + SR * it, 0);
+            if (r_begin + SR * it + 16 < r_end) compute(int(it & 1), r_begin + SR * it, 1);
+            if (it + 1 < n_st) deposit(int((it + 1) & 1));
+            __syncthreads();
         }
     }
     float *out = partial + int64_t(blockIdx.x) * mpad * npad;
@@ -1012,12 +1033,20 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
     const int64_t rows_per_wg = ((N + nb - 1) / nb + 1) & ~int64_t(1);  // even: steps are row pairs
     const int nt = (n + 31) / 32, mt = (k + 31) / 32;
     float *partial = static_cast<float *>(workspace);
-    if (g_gemm_split.load(std::memory_order_relaxed) != 0 && k == 200 && nt == 2 && !drop) {
-        // split-bf16 products for the weight gradient of the GCN's second layer (16-row K steps).  Without the
-        // fused dropout only: with it both operands are split AND every element of A is hashed on the vector
-        // ALU, which then outweighs the 6 MFMAs per tile pair (0.87 against 0.84 ms for the fp32 MFMA kernel at c4).
-        const int64_t rpw = ((N + nb - 1) / nb + 15) & ~int64_t(15);
-        k_gemm_tn_split<2, false><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rpw, partial, Drop{});
+    if (g_gemm_split.load(std::memory_order_relaxed) != 0 && k == 200 && nt == 2 && lda == k && ldg == n && n % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(G) % 16 == 0) {
+        // split-bf16 products for the weight gradient of the GCN's second layer (16-row K steps through LDS)
+        const int64_t rpw = ((N + nb - 1) / nb + 31) & ~int64_t(31);
+        const size_t lb = sizeof(float) * 2 * (32 * (k + 4) + 32 * (n + 4));
+        if (drop) {
+            TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_split<2, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));
+            k_gemm_tn_split<2, true><<<nb, 256, lb, s>>>(A, G, N, k, n, rpw, partial, *drop);
+        } else {
+            TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_split<2, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));
+            k_gemm_tn_split<2, false><<<nb, 256, lb, s>>>(A, G, N, k, n, rpw, partial, Drop{});
+        }
         TGCN_HIP_CHECK(hipGetLastError());
         k_gemm_tn_reduce<<<(k * n + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mt, 32 * nt, k, n, C, ldc);
         TGCN_HIP_CHECK(hipGetLastError());
