@@ -81,11 +81,6 @@ __device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t c
     return h >= d.thresh ? v * d.scale : 0.f;
 }
 
-__device__ __forceinline__ float drop_apply(float v, uint32_t s_lo, uint32_t s_hi, int64_t row, int col,
-                                            const Drop &d) {
-    return drop_elem(v, drop_row_key(s_lo, s_hi, row), drop_col_term(col), d);
-}
-
 // ---------------------------------------------------------------------------------------------
 // C[N, n] = A[N, k] @ Bs, where Bs[kk][j] is the small operand staged in LDS as [kpad][npad].
 // One wave per 32 rows, NT tiles of 32 columns each (npad = 32*NT).  TRANS_B selects how the small

@@ -392,7 +392,7 @@ constexpr unsigned kOobOffset = 0xFFFFFF00u;   // beyond any buffer this kernel 
 
 template <int G, int U>
 __global__ __launch_bounds__(256) void k_spmm_subb(
-    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
+    const WorkItem *__restrict__ items, int n_items,
     const int2 *__restrict__ cv, const float *__restrict__ X, unsigned ldx4 /* row stride in bytes */,
     unsigned x_bytes, int F, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy,
     float *__restrict__ carry, int64_t ldc, const int4 *__restrict__ row_info) {
@@ -842,11 +842,11 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
             // hold ~10 entries and every started group of U is gathered in full
             // (with the rows of a block sorted by degree U = 4 is still the best: 2 / 8 measured 10 % / 8 % slower)
             if (F <= 64)
-                k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
+                k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
                                                             static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
                                                             blk.row_info);
             else
-                k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, static_cast<unsigned>(ldx * 4),
+                k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
                                                             static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
                                                             blk.row_info);
         } else if (VEC == 4 && F <= 128 && narrow_from_env()) {

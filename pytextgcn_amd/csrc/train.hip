@@ -219,7 +219,7 @@ __global__ void k_ce_final(const float *__restrict__ partial, int n, float inv_c
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        if (static_cast<int>(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
     if (threadIdx.x == 0) *loss = red[0] * inv_count;
