@@ -32,6 +32,7 @@ CONFIGS = {
     "c2": (100_000, 2_000_000, 200, 64),
     "c4": (2_000_000, 50_000_000, 200, 64),
     "c3": (1_000_000, 24_000_000, 200, 219),     # DBpedia-shaped: V = 30 k, 219 classes (l3)
+    "c5": (8_000_000, 200_000_000, 256, 64),     # generic power law (no word / document structure), h = 256
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
@@ -46,7 +47,58 @@ def parse():
     p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
     p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 32)
     p.add_argument("--no-hbm-activity", action="store_true", help="skip the live memory-controller measurement")
+    p.add_argument("--launch-check", action="store_true",
+                   help="rendezvous only: every rank joins the group, rank 0 prints {launch_check, n_gpus}; no GPU work")
     return p.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python3 bench.py --gpus N` (N > 1) without a rendezvous environment: start one rank per GPU as a CHILD
+    `python -m torch.distributed.run` (never an exec, and before this process has made any GPU call), relay the one
+    JSON line rank 0 prints and hand back the child's return code.  Under torch.distributed.run (WORLD_SIZE set) this
+    function is not reached."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)       # stderr passes straight through
+    record = None
+    for ln in res.stdout.decode("utf-8", "replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                record = ln
+            except ValueError:
+                pass
+    if record is not None:
+        print(record, flush=True)
+    elif res.returncode == 0:
+        print("bench.py: the ranks exited cleanly but printed no record", file=sys.stderr)
+        return 1
+    return res.returncode
+
+
+def launch_check(world, rank):
+    """--launch-check: the rendezvous and the record relay without any GPU work (CPU test of the N > 1 launch)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    ok = t.item() == world * (world - 1) / 2
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": bool(ok), "n_gpus": world}), flush=True)
+    return 0 if ok else 1
 
 
 def cpu_model():
@@ -292,7 +344,7 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
     gen = torch.Generator(device=dev).manual_seed(7)
     y_full = torch.randint(0, n_classes, (N,), device=dev, generator=gen)
     u = torch.rand(N, device=dev, generator=gen)
-    is_doc = ~sg.part.hub_mask
+    is_doc = ~sg.part.hub_mask if not bool(sg.part.hub_mask.all()) else torch.ones_like(sg.part.hub_mask)
     y_l = sg.scatter_rows(y_full)
     train_l = sg.scatter_rows(is_doc & (u < 0.8))
     val_l = sg.scatter_rows(is_doc & (u >= 0.8) & (u < 0.9))
@@ -399,6 +451,14 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10, extra=False):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain `python3 bench.py --gpus N`: build once here (hipcc, no GPU call), then one child rank per GPU
+        from pytextgcn_amd import build as _build
+        if not args.launch_check and not os.path.exists(_build.LIB_PATH):
+            _build.build()
+        sys.exit(launch_ranks(args))
+    if args.launch_check:
+        sys.exit(launch_check(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))))
     # stdout carries exactly ONE line (the JSON record): everything else that writes to file descriptor 1
     # -- RCCL prints a version banner there when a communicator is created -- is sent to stderr
     sys.stdout.flush()
@@ -407,10 +467,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world          # under torch.distributed.run the world size is authoritative
     # a checkout without binaries (the .so is git-ignored): local rank 0 compiles it once (hipcc is on the
     # GPU box, os.replace makes the file appear atomically), the other ranks wait for the file
     from pytextgcn_amd import build as _build
@@ -442,13 +499,18 @@ def main():
 
     N, E, F, C = CONFIGS[args.config]
     gen_kw = dict(vocab_frac=0.03, doc_word_share=0.9) if args.config == "c3" else {}
+
+    def make_graph(features):
+        if args.config == "c5":       # no word / document structure: every node is an ordinary node
+            return synth.power_law_graph(N, E, seed=44, device=dev, n_classes=C, features=features)
+        return synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features=features, **gen_kw)
     if world == 1:
-        g = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, **gen_kw)
+        g = make_graph("sparse_identity")
     else:
         # rank 0 generates the graph and broadcasts it, so every rank partitions identical bytes
         from pytextgcn_amd.data import Data
         if rank == 0:
-            g0 = synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features="none", **gen_kw)
+            g0 = make_graph("none")
             coo, attr = g0.edge_index.t().contiguous(), g0.edge_attr.contiguous()
             meta = torch.tensor([g0.n_vocab], device=dev)
             del g0
@@ -489,7 +551,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        hubs = torch.arange(N, device=dev) < g.n_vocab          # word nodes: replicated operand block
+        # word nodes: replicated operand block; a graph without them (c5) has no hub structure -> every node's
+        # rows may be needed anywhere: the halo exchange sends the referenced ones
+        hubs = torch.arange(N, device=dev) < g.n_vocab if g.n_vocab > 0 else None
         sg = ShardedGraph(g.edge_index, g.edge_attr, N, group=dist.group.WORLD, hubs=hubs)
         x = torch.randn(sg.n_local, F, device=dev, generator=gen)
         gout = torch.randn(sg.n_local, F, device=dev, generator=gen)
@@ -636,7 +700,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: synthetic PMI/TF-IDF word-doc graph, N={N}, E={E}, "
+            "config": {"workload": f"{args.config}: synthetic "
+                                   f"{'power-law graph' if args.config == 'c5' else 'PMI/TF-IDF word-doc graph'}, N={N}, E={E}, "
                                    f"nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G",
                        "parallelism": parallelism},
             "roofline": roofline,

@@ -150,9 +150,11 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
 
 
 def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", alpha: float = 2.1,
-                    symmetric: bool = True) -> Data:
+                    symmetric: bool = True, n_classes: int = 0, features: str = "none") -> Data:
     """Generic power-law graph (config c5 of BASELINE.json): endpoint i drawn with probability
-    ~ degree weight d_i ~ Zipf(alpha) clipped to [1, 1e6]; weights U(0, 1]; no loops, no dups."""
+    ~ degree weight d_i ~ Zipf(alpha) clipped to [1, 1e6]; weights U(0, 1]; no loops, no dups.
+    `n_classes` > 0 adds uniform labels and 80/10/10 masks over ALL nodes (there are no word nodes here);
+    `features="sparse_identity"` the one-hot feature matrix of text2graph.py:179."""
     device = torch.device(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -189,7 +191,18 @@ def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", al
         w = w.repeat_interleave(2)
     else:
         coo = torch.stack([a, b], 1)
-    return Data(x=None, edge_index=coo.T, edge_attr=w.float(), n_vocab=0)
+    g = Data(x=None, edge_index=coo.T, edge_attr=w.float(), n_vocab=0)
+    if n_classes > 0:
+        g.y = torch.randint(0, n_classes, (N,), generator=gen, device=device)
+        u = torch.rand(N, generator=gen, device=device)
+        g.train_mask, g.val_mask, g.test_mask = u < 0.8, (u >= 0.8) & (u < 0.9), u >= 0.9
+        g.n_classes = n_classes
+    if features == "sparse_identity":
+        ar = torch.arange(N, device=device)
+        g.x = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=device), (N, N)).coalesce()
+    elif features != "none":
+        raise ValueError(features)
+    return g
 
 
 def random_graph(n_nodes: int, n_edges: int, seed: int = 0, device="cpu", self_loops: int = 0,

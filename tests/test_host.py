@@ -226,3 +226,41 @@ def test_mask_count_cache_is_keyed_by_object_not_by_address():
     assert _mask_count(keep) == 10 and _mask_count(keep) == 10
     keep[0] = False                                   # in-place edit bumps the version
     assert _mask_count(keep) == 9
+
+
+def test_bench_launches_its_own_ranks_for_n_gt_1():
+    """`python3 bench.py --gpus 2` as a plain command (no torch.distributed.run around it): bench.py starts the
+    ranks itself as a child process, relays exactly one JSON line and the return code.  `--launch-check` stops after
+    the rendezvous, so this runs without a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec == {"launch_check": True, "n_gpus": 2}
+
+
+def test_bench_knows_every_baseline_configuration():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.CONFIGS["c4"][:3] == (2_000_000, 50_000_000, 200)
+    assert bench.CONFIGS["c5"][:3] == (8_000_000, 200_000_000, 256)
+    assert bench.CONFIGS["c2"][:3] == (100_000, 2_000_000, 200)
+
+
+def test_power_law_graph_carries_labels_and_masks():
+    g = synth.power_law_graph(2000, 30000, seed=3, n_classes=5, features="sparse_identity")
+    assert g.n_vocab == 0 and g.y.shape == (2000,) and int(g.y.max()) < 5
+    assert int(g.train_mask.sum() + g.val_mask.sum() + g.test_mask.sum()) == 2000
+    assert g.x.is_sparse and g.x.shape == (2000, 2000)

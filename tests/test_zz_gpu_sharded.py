@@ -57,3 +57,23 @@ def test_two_rccl_ranks_one_per_gpu(cuda, monkeypatch, exchange):
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     monkeypatch.setenv("TGCN_EXCHANGE", exchange)
     run(2, ["wordoc_big", "wordoc_allhubs"], "nccl", device="cuda:{rank}")
+
+
+def test_bench_two_ranks_as_a_plain_command(cuda):
+    """`python3 bench.py --gpus 2 --config c2` with no launcher around it: two gloo ranks sharing cuda:0 rehearse the
+    whole N > 1 bench (self-launch, graph broadcast, partition, exchange-form trial steps, timed region, sharded epoch)
+    and rank 0's single JSON line comes back through the parent."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TGCN_BENCH_BACKEND="gloo", TGCN_BENCH_DEVICE="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2",
+                          "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=env, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["unit"] == "edges/s"
+    assert rec["exchange_selection"]["chosen"] in rec["exchange_selection"]["ms_per_step"]
