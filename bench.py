@@ -424,6 +424,16 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10, extra=False):
         out["local_B_own_rows"] = phase(lambda: B.spmm(xbuf, None, x2=x[hp:] if rp > 0 else None))
         out["all_gather_into_tensor"] = phase(lambda: dist.all_gather_into_tensor(xbuf, x[:hp].contiguous()))
         out["reduce_scatter_tensor"] = phase(lambda: dist.reduce_scatter_tensor(rs_out, partial))
+        d0 = sg.dirs[0]
+        direct = sg._stream_ordered(x)
+
+        def halo_gather():
+            pack = x[:hp].index_select(0, d0.send_slots)
+            recv, work = sg._all_to_all_v(pack, d0.need_counts_l, d0.send_counts_l, direct)
+            work.wait()
+            xbuf.index_copy_(0, d0.need_cols, recv)
+        out["halo_gather_referenced_rows_only"] = phase(halo_gather)
+        out["rows_received_per_spmm"] = sg.exchange_rows()
         out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
         return out
 
@@ -572,8 +582,9 @@ def main():
         ops_b = [op for op in sg.ops[-1] if op is not None]
         bytes_fwd = sum(op.algorithmic_bytes(F) for op in ops_f) + 4 * F
         bytes_bwd = sum(op.algorithmic_bytes(F) for op in ops_b)
-        parallelism = (f"row{world}: hubs(words) replicated by all-gather, hub rows reduce-scattered"
-                       f" (exchange={sg.exchange})")
+        parallelism = (f"row{world}: " + ("hubs(words) replicated, hub rows reduce-scattered" if sg.rp > 0 else
+                                          "no hub structure: operand rows exchanged") +
+                       f" (exchange={sg.exchange}, A_r row chunks={sg.rs_chunks})")
 
     def barrier():
         if dist is not None:
@@ -585,22 +596,29 @@ def main():
     # steps of each decide (max over ranks, the same answer on every rank).  TGCN_EXCHANGE pins the form.
     exchange_selection = None
     if world > 1 and "TGCN_EXCHANGE" not in os.environ:
+        forms = list(sg.EXCHANGES)
+        chunkings = [1, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
         trial = {}
-        for mode in ("collective", "p2p"):
-            sg.exchange = mode
-            step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(3):
+        for K in chunkings:
+            sg.set_rs_chunks(K)
+            for mode in forms:
+                sg.exchange = mode
                 step()
-            barrier()
-            t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            trial[mode] = t.item()
-        sg.exchange = min(trial, key=trial.get)
-        exchange_selection = {"ms_per_step": trial, "chosen": sg.exchange}
-        parallelism = (f"row{world}: hubs(words) replicated by all-gather, hub rows reduce-scattered"
-                       f" (exchange={sg.exchange}, the faster of the two forms in {trial})")
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial[f"{mode}/{K}"] = t.item()
+        best = min(trial, key=trial.get)
+        sg.exchange = best.split("/")[0]
+        sg.set_rs_chunks(int(best.split("/")[1]))
+        exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows()}
+        parallelism = (f"row{world}: " + ("hubs(words) replicated, hub rows reduce-scattered" if sg.rp > 0 else
+                                          "no hub structure: operand rows exchanged") +
+                       f" (exchange form / A_r row chunks = {best}, the fastest of {trial})")
     for _ in range(args.warmup):
         step()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]

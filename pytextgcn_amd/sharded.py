@@ -91,6 +91,16 @@ class HipEngine:
         return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
 
 
+class _Done:
+    """A finished transfer (the staged exchanges complete before they return)."""
+    @staticmethod
+    def wait():
+        return True
+
+
+_DONE = _Done()
+
+
 def _wrap64(v: int) -> int:
     """A 64-bit constant as the signed value torch.int64 holds."""
     v &= (1 << 64) - 1
@@ -178,14 +188,44 @@ class Partition:
         return out
 
 
+class _Chunk:
+    """One row chunk of A_r (hub slots s with s % K == k) and the lists of its pruned reduce-scatter."""
+    __slots__ = ("op", "k", "ck", "n_own", "touch_rows", "touch_counts", "recv_counts", "recv_pos")
+
+    def __init__(self, op, k, ck, n_own):
+        self.op, self.k, self.ck, self.n_own = op, k, ck, n_own
+        self.touch_rows = self.touch_counts = self.recv_counts = self.recv_pos = None
+
+
+class _Direction:
+    """The local operators of M (or of M^T) on one rank and what their exchange needs."""
+
+    def __init__(self):
+        self.A_entries = None          # (row = owner * hp + slot, col, w) of A_r, kept to cut row chunks
+        self.B = None
+        self.chunks = {}               # K -> [_Chunk] (K = 1: the whole A_r)
+        self.need_cols = None          # halo: gathered-block rows (owner * hp + slot) B_r references, sorted
+        self.need_counts = None        #       ... how many of them every rank owns
+        self.send_slots = None         #       own hub slots every peer needs, concatenated in rank order
+        self.send_counts = None
+
+    @property
+    def A(self):
+        ch = self.chunks.get(1)
+        return ch[0].op if ch else None
+
+
 class ShardedGraph:
     _CHUNK = 1 << 23      # edges per pass of the local-operator construction (transients stay O(chunk))
+    EXCHANGES = ("collective", "p2p", "halo")
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
                  group=None, hubs: Optional[Tensor] = None, add_self_loops=True,
                  normalize: bool = True, engine=None, symmetric: Optional[bool] = None):
         """`symmetric`: None = find out (an edge-multiset fingerprint of M against M^T); True / False skips
-        the test (TextGCN graphs are symmetric by construction, text2graph.py:148-171)."""
+        the test (TextGCN graphs are symmetric by construction, text2graph.py:148-171).
+        Construction is COLLECTIVE: every rank of `group` must build the graph at the same time (the index lists of
+        the halo exchange are swapped between the ranks)."""
         self.group = group if group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
@@ -195,6 +235,8 @@ class ShardedGraph:
         part = Partition(edge_index, num_nodes, self.world, hubs)
         self.part = part
         self.hp, self.rp, self.n_local = part.hp, part.rp, part.n_local
+        if self.hp == 0:
+            raise ValueError("a sharded graph needs at least one hub node per rank (hubs=None makes every node one)")
         self.owned = part.owned(self.rank)
         self.real = self.owned >= 0
         self._all_real = None                                 # resolved at the first bias gradient (colsum_real)
@@ -209,20 +251,35 @@ class ShardedGraph:
         self._loops = loops
         self.symmetric = bool(symmetric) if symmetric is not None else \
             self._is_symmetric(edge_index, edge_weight)
-        self.ops = [self._local_ops(edge_index, edge_weight, transpose=False)]
+        self.dirs = [self._local_ops(edge_index, edge_weight, transpose=False)]
         if not self.symmetric:
-            self.ops.append(self._local_ops(edge_index, edge_weight, transpose=True))
+            self.dirs.append(self._local_ops(edge_index, edge_weight, transpose=True))
         self._dis = self._loop_w = None
-        self.plan = self.ops[0][1]            # the larger local operator (for reporting)
-        # "collective": RCCL all-gather + reduce-scatter (default).  "p2p": the same exchange as direct
-        # pairwise transfers (batched send/recv, all-to-all + local sum) -- on a full xGMI mesh every pair
-        # has its own link; kept selectable (TGCN_EXCHANGE) until 8-GPU timings say which is faster.
+        self.plan = self.dirs[0].B            # the larger local operator (for reporting)
+        # Forms of the exchange (all give the same sums; "p2p" and "halo" add the ranks' partial rows in rank order,
+        # bit for bit alike; RCCL's reduce-scatter adds them in an order of its own):
+        #   "collective"  RCCL all-gather + reduce-scatter of the whole hub block;
+        #   "p2p"         the same rows as direct pairwise transfers (batched send / recv, all-to-all + local sum):
+        #                 on a full xGMI mesh every pair of GPUs has its own link;
+        #   "halo"        index lists built here, once: a rank receives only the hub rows its B_r references and sends
+        #                 only the partial rows its A_r touches (all_to_all_single with split sizes).  For graphs
+        #                 without hub structure (hubs=None) this is the true halo exchange.
+        # TGCN_EXCHANGE pins the form, TGCN_RS_CHUNKS the number of row chunks A_r runs in (each chunk's
+        # reduce-scatter starts when its rows are finished); bench.py times a few steps of each and keeps the fastest.
         import os
+        self._build_halo_lists()
+        self.rs_chunks = 1
+        self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
         self.exchange = os.environ.get("TGCN_EXCHANGE", "collective")
-        if self.exchange not in ("collective", "p2p"):
-            raise ValueError("TGCN_EXCHANGE must be 'collective' or 'p2p'")
+        if self.exchange not in self.EXCHANGES:
+            raise ValueError(f"TGCN_EXCHANGE must be one of {self.EXCHANGES}")
         self._xbuf = {}
         self._stage = {}
+
+    @property
+    def ops(self):
+        """[(A_r, B_r)] of M (and of M^T when M is not symmetric)."""
+        return [(d.A, d.B) for d in self.dirs]
 
     @classmethod
     def from_data(cls, g, group=None, **kw) -> "ShardedGraph":
@@ -236,7 +293,9 @@ class ShardedGraph:
     # ---- construction ---------------------------------------------------------------------------
     def _chunks(self, edge_index: Tensor, edge_weight: Optional[Tensor]):
         """(source, target, w_hat) of the non-loop entries of M, a chunk of edges at a time: w_hat = w * (dis[s]
-        * dis[t]) -- the association of tgcn_plan_create, which keeps a symmetric graph bitwise symmetric."""
+        * dis[t]) -- the association of tgcn_plan_create, which keeps a symmetric graph bitwise symmetric.  (The
+        degrees behind `dis` are summed chunk-wise by tgcn_gcn_norm, so the weights agree with the single-device
+        plan's to fp32 rounding, not bit for bit.)"""
         E = edge_index.size(1)
         for lo in range(0, E, self._CHUNK):
             hi = min(E, lo + self._CHUNK)
@@ -262,11 +321,12 @@ class ShardedGraph:
                 sums[i][1] = (sums[i][1] + _entry_hash(s, t, bits, ks)) & ((1 << 64) - 1)
         return all(a == b for a, b in sums)
 
-    def _local_ops(self, edge_index: Tensor, edge_weight: Optional[Tensor], transpose: bool):
+    def _local_ops(self, edge_index: Tensor, edge_weight: Optional[Tensor], transpose: bool) -> _Direction:
         """A_r and B_r of M (or of M^T), cut out of the edge list chunk by chunk."""
         p, r, W, hp, rp = self.part, self.rank, self.world, self.hp, self.rp
         dev = edge_index.device
         parts_a, parts_b = [], []
+        need = torch.zeros(W * hp, dtype=torch.bool, device=dev)      # gathered-block rows B_r reads
         for s, t, w in self._chunks(edge_index, edge_weight):
             if transpose:
                 s, t = t, s
@@ -279,13 +339,17 @@ class ShardedGraph:
             # B: own rows <- all hubs + own regular columns (hub <- regular entries all live in A)
             b = t_mine & (s_hub | (s_mine & ~t_hub))
             tb, sb = t[b], s[b]
+            sb_hub = p.hub_mask[sb]
+            need[p.hub_col[sb[sb_hub]]] = True
             parts_b.append((torch.where(p.hub_mask[tb], p.slot[tb], hp + p.slot[tb]),
-                            torch.where(p.hub_mask[sb], p.hub_col[sb], p.reg_col[sb]), w[b]))
+                            torch.where(sb_hub, p.hub_col[sb], p.reg_col[sb]), w[b]))
         if self._loops:
             # one loop per own node, after the edges (the tail position add_remaining_self_loops gives them)
             own = self.owned[self.real]
             lrow = torch.nonzero(self.real).flatten()
-            lcol = torch.where(p.hub_mask[own], p.hub_col[own], p.reg_col[own])
+            own_hub = p.hub_mask[own]
+            lcol = torch.where(own_hub, p.hub_col[own], p.reg_col[own])
+            need[lcol[own_hub]] = True
             lw = self._loop_w[own]
             if self._dis is not None:
                 lw = lw * (self._dis[own] * self._dis[own])
@@ -295,12 +359,74 @@ class ShardedGraph:
             if not parts:
                 return torch.empty(0, dtype=torch.float32 if k == 2 else torch.int64, device=dev)
             return torch.cat([q[k] for q in parts])
-        A = None
+        d = _Direction()
         if rp > 0:
-            A = self.engine.make_op(cat(parts_a, 0), cat(parts_a, 1), cat(parts_a, 2), W * hp, rp)
+            d.A_entries = (cat(parts_a, 0), cat(parts_a, 1), cat(parts_a, 2))
+            d.chunks[1] = [_Chunk(self.engine.make_op(*d.A_entries, W * hp, rp), 0, hp, hp)]
         del parts_a
-        B = self.engine.make_op(cat(parts_b, 0), cat(parts_b, 1), cat(parts_b, 2), hp + rp, W * hp + rp)
-        return A, B
+        d.B = self.engine.make_op(cat(parts_b, 0), cat(parts_b, 1), cat(parts_b, 2), hp + rp, W * hp + rp)
+        d.need_cols = torch.nonzero(need).flatten()
+        return d
+
+    # ---- index lists of the halo exchange (built once; collective) ---------------------------------
+    def _comm_device(self):
+        """Where small index tensors travel: RCCL moves device memory only, a host-serviced backend host memory."""
+        return self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def _swap_lists(self, idx: Tensor, counts: Tensor) -> Tuple[Tensor, Tensor]:
+        """Every rank hands every peer q the slice of `idx` that concerns q (`counts[q]` entries, rank order) and
+        gets the peers' slices for itself: (received indices concatenated in rank order, their counts)."""
+        cd = self._comm_device()
+        counts = counts.to(cd)
+        got_counts = torch.empty_like(counts)
+        dist.all_to_all_single(got_counts, counts, group=self.group)
+        out_sizes, in_sizes = [int(v) for v in got_counts.tolist()], [int(v) for v in counts.tolist()]
+        got = torch.empty(sum(out_sizes), dtype=torch.int64, device=cd)
+        dist.all_to_all_single(got, idx.to(cd).contiguous(), out_sizes, in_sizes, group=self.group)
+        return got.to(self.device), got_counts.to(self.device)
+
+    def _build_halo_lists(self) -> None:
+        hp, W = self.hp, self.world
+        for d in self.dirs:
+            owner = d.need_cols // hp
+            d.need_counts = torch.bincount(owner, minlength=W)
+            # tell every owner which of its slots this rank reads; learn which of the own slots the peers read
+            d.send_slots, d.send_counts = self._swap_lists(d.need_cols - owner * hp, d.need_counts)
+            d.need_counts_l = [int(v) for v in d.need_counts.tolist()]
+            d.send_counts_l = [int(v) for v in d.send_counts.tolist()]
+
+    def set_rs_chunks(self, K: int) -> None:
+        """Run A_r as K row chunks (hub slot s belongs to chunk s % K, so the chunks are alike in weight); the
+        reduce-scatter of a chunk is issued as soon as its rows are finished and overlaps the remaining chunks.
+        Collective (the pruned reduce-scatter's index lists are swapped)."""
+        K = max(1, min(int(K), self.hp))
+        W, hp, rp = self.world, self.hp, self.rp
+        for d in self.dirs:
+            if d.A_entries is None:
+                continue
+            row, col, w = d.A_entries
+            owner, slot = row // hp, row % hp
+            if K not in d.chunks:
+                ck = (hp + K - 1) // K
+                chunks = []
+                for k in range(K):
+                    sel = (slot % K) == k
+                    op = self.engine.make_op(owner[sel] * ck + slot[sel] // K, col[sel], w[sel], W * ck, rp)
+                    chunks.append(_Chunk(op, k, ck, len(range(k, hp, K))))
+                d.chunks[K] = chunks
+            for ch in d.chunks[K]:
+                if ch.touch_rows is not None:
+                    continue
+                sel = (slot % K) == ch.k
+                touched = torch.unique(owner[sel] * ch.ck + slot[sel] // K)        # sorted: rank-major
+                ch.touch_rows = touched
+                t_owner = touched // ch.ck
+                counts = torch.bincount(t_owner, minlength=W)
+                got, got_counts = self._swap_lists(touched - t_owner * ch.ck, counts)
+                ch.touch_counts = [int(v) for v in counts.tolist()]
+                ch.recv_counts = [int(v) for v in got_counts.tolist()]
+                ch.recv_pos = got                          # positions inside the chunk's own rows, rank order
+        self.rs_chunks = K
 
     # ---- data movement ---------------------------------------------------------------------------
     def scatter_rows(self, full: Tensor) -> Tensor:
@@ -343,51 +469,124 @@ class ShardedGraph:
             self._stage[key] = buf
         return buf
 
+    def _gather_buffer(self, x_local: Tensor, halo: bool) -> Tensor:
+        """The gathered hub block [W * hp, F], one per width (layer-1 / layer-2 widths alternate).  The halo form
+        has its own, zero-filled once: it only ever writes the rows B_r references, and the rest must stay finite
+        (the dense hot block of a local operator multiplies EVERY operand row by a possibly zero weight)."""
+        F = x_local.size(1)
+        key = (F, x_local.dtype, x_local.device, halo)
+        xbuf = self._xbuf.get(key)
+        if xbuf is None:
+            make = torch.zeros if halo else torch.empty
+            xbuf = make(self.world * self.hp, F, dtype=x_local.dtype, device=x_local.device)
+            self._xbuf[key] = xbuf
+        return xbuf
+
+    def _start_gather(self, d: _Direction, x_local: Tensor):
+        """Start bringing the hub rows this rank's B_r reads into the gather buffer.  Returns (buffer, finish):
+        `finish()` makes the current stream wait for the rows."""
+        hp = self.hp
+        shard = x_local[:hp]
+        direct = self._stream_ordered(x_local)
+        if self.exchange == "collective":
+            xbuf = self._gather_buffer(x_local, False)
+            work = dist.all_gather_into_tensor(xbuf, shard, group=self.group, async_op=True)
+            return xbuf, work.wait
+        if self.exchange == "p2p":
+            xbuf = self._gather_buffer(x_local, False)
+            works = self._all_gather_p2p(xbuf, shard) if direct else self._all_gather_p2p_staged(xbuf, shard)
+            return xbuf, lambda: [w.wait() for w in works]
+        # halo: only the rows somebody reads travel
+        xbuf = self._gather_buffer(x_local, True)
+        pack = shard.index_select(0, d.send_slots)
+        recv, work = self._all_to_all_v(pack, d.need_counts_l, d.send_counts_l, direct)
+
+        def finish():
+            work.wait()
+            xbuf.index_copy_(0, d.need_cols, recv)
+        return xbuf, finish
+
+    def _all_to_all_v(self, src: Tensor, out_sizes, in_sizes, direct: bool):
+        """all_to_all_single with split sizes (rows); device tensors over a host-serviced backend go through pinned
+        host memory with blocking copies (see `_stream_ordered`).  Returns (received rows, work)."""
+        shape = (sum(out_sizes),) + tuple(src.shape[1:])
+        if direct:
+            dst = torch.empty(shape, dtype=src.dtype, device=src.device)
+            return dst, dist.all_to_all_single(dst, src, out_sizes, in_sizes, group=self.group, async_op=True)
+        h_src = self._host_stage("a2av_src", src.shape, src.dtype)
+        h_dst = self._host_stage("a2av_dst", shape, src.dtype)
+        h_src.copy_(src)                                            # synchronous: `src` is complete
+        dist.all_to_all_single(h_dst, h_src, out_sizes, in_sizes, group=self.group)
+        dst = torch.empty(shape, dtype=src.dtype, device=src.device)
+        dst.copy_(h_dst)
+        return dst, _DONE
+
+    def _start_reduce(self, ch: _Chunk, partial: Tensor):
+        """Start the reduce-scatter of one chunk of hub partial sums [W * ck, F].  Returns finish(y_hub): waits and adds
+        the sums of this rank's rows of the chunk (slots k, k + K, ...) to `y_hub`."""
+        W, ck, F = self.world, ch.ck, partial.size(1)
+        direct = self._stream_ordered(partial)
+        K = self.rs_chunks
+
+        def add_to(y_hub: Tensor, acc: Tensor):
+            if K == 1:
+                y_hub += acc
+            else:
+                y_hub[ch.k::K] += acc[:ch.n_own]
+        if self.exchange == "collective":
+            out = torch.empty(ck, F, dtype=partial.dtype, device=partial.device)
+            work = dist.reduce_scatter_tensor(out, partial, group=self.group, async_op=True)
+
+            def finish(y_hub):
+                work.wait()
+                add_to(y_hub, out)
+            return finish
+        if self.exchange == "p2p":
+            sizes = [ck] * W
+            recv, work = self._all_to_all_v(partial, sizes, sizes, direct)
+
+            def finish(y_hub):
+                work.wait()
+                acc = recv[:ck].clone()                     # the ranks' partial rows, added in rank order
+                for q in range(1, W):
+                    acc += recv[q * ck:(q + 1) * ck]
+                add_to(y_hub, acc)
+            return finish
+        # halo: only rows with entries travel; absent rows are exact zeros in the other forms
+        pack = partial.index_select(0, ch.touch_rows)
+        recv, work = self._all_to_all_v(pack, ch.recv_counts, ch.touch_counts, direct)
+
+        def finish(y_hub):
+            work.wait()
+            acc = torch.zeros(ck, F, dtype=partial.dtype, device=partial.device)
+            off = 0
+            for q in range(W):                              # rank order; a rank's rows are distinct
+                n = ch.recv_counts[q]
+                if n:
+                    acc.index_add_(0, ch.recv_pos[off:off + n], recv[off:off + n])
+                off += n
+            add_to(y_hub, acc)
+        return finish
+
     def spmm(self, x_local: Tensor, bias: Optional[Tensor] = None, transpose: bool = False) -> Tensor:
-        A, B = self.ops[1 if (transpose and not self.symmetric) else 0]
-        W, hp, rp = self.world, self.hp, self.rp
+        d = self.dirs[1 if (transpose and not self.symmetric) else 0]
+        hp, rp = self.hp, self.rp
         if x_local.shape[0] != self.n_local:
             raise ValueError(f"operand has {x_local.shape[0]} rows, this rank owns {self.n_local}")
         x_local = x_local.contiguous()
-        F = x_local.size(1)
-        key = (F, x_local.dtype, x_local.device)
-        xbuf = self._xbuf.get(key)
-        if xbuf is None:                       # gathered hub block only: the own rows are read in place
-            xbuf = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
-            self._xbuf[key] = xbuf             # one per width: layer-1 / layer-2 widths alternate
-        if hp == 0:
-            raise ValueError("a sharded graph needs at least one hub node per rank")
-        p2p = self.exchange == "p2p"
-        direct = self._stream_ordered(x_local)
-        if not p2p:
-            ag = [dist.all_gather_into_tensor(xbuf, x_local[:hp], group=self.group, async_op=True)]
-        elif direct:
-            ag = self._all_gather_p2p(xbuf, x_local[:hp])
-        else:
-            ag = self._all_gather_p2p_staged(xbuf, x_local[:hp])
-        rs = rs_out = None
-        if A is not None:
-            partial = A.spmm(x_local[hp:])                       # overlaps the all-gather
-            for w in ag:
-                w.wait()
-            if p2p and direct:
-                # reduce-scatter as an all-to-all of the W slices (every pair of GPUs talks over its own
-                # xGMI link at the same time) + a local sum in rank order
-                rs_out = torch.empty(W * hp, F, dtype=x_local.dtype, device=x_local.device)
-                rs = dist.all_to_all_single(rs_out, partial, group=self.group, async_op=True)
-            elif p2p:
-                rs_out, rs = self._all_to_all_staged(partial)
-            else:
-                rs_out = torch.empty(hp, F, dtype=x_local.dtype, device=x_local.device)
-                rs = dist.reduce_scatter_tensor(rs_out, partial, group=self.group, async_op=True)
-        else:
-            for w in ag:
-                w.wait()
+        xbuf, gathered = self._start_gather(d, x_local)
+        pending = []
+        if d.A is not None:
+            # hub rows x own regular columns, chunk by chunk: a chunk's reduce-scatter is issued behind its SpMM and
+            # runs while the next chunks (and then B_r) are computed
+            xr = x_local[hp:]
+            for ch in d.chunks[self.rs_chunks]:
+                pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
+        gathered()
         # split operand: hub columns from the gathered block, own regular columns straight from x_local
-        y = B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)   # overlaps the reduce-scatter
-        if rs is not None:
-            rs.wait()
-            y[:hp] += rs_out.view(W, hp, F).sum(0) if p2p else rs_out
+        y = d.B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)   # overlaps the reduce-scatter
+        for finish in pending:
+            finish(y[:hp])
         return y
 
     def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):
@@ -426,20 +625,16 @@ class ShardedGraph:
         xbuf.copy_(recv)                                            # host -> device, synchronous
         return []
 
-    def _all_to_all_staged(self, partial: Tensor):
-        """all_to_all_single of the hub partial sums through pinned host memory (see above)."""
-        src = self._host_stage("a2a_src", partial.shape, partial.dtype)
-        dst = self._host_stage("a2a_dst", partial.shape, partial.dtype)
-        src.copy_(partial)                                          # synchronous: `partial` is complete
-        dist.all_to_all_single(dst, src, group=self.group)
-        out = torch.empty_like(partial)
-        out.copy_(dst)
-
-        class _Done:
-            @staticmethod
-            def wait():
-                return True
-        return out, _Done
+    def exchange_rows(self) -> dict:
+        """Rows per SpMM this rank receives in each form (what the halo lists prune), for reports."""
+        d = self.dirs[0]
+        out = {"gather_all": (self.world - 1) * self.hp,
+               "gather_halo": int(sum(d.need_counts_l)) - d.need_counts_l[self.rank]}
+        if d.A is not None:
+            chs = d.chunks[self.rs_chunks]
+            out["reduce_all"] = (self.world - 1) * self.hp
+            out["reduce_halo"] = int(sum(sum(c.recv_counts) - c.recv_counts[self.rank] for c in chs))
+        return out
 
     def colsum_real(self, g_local: Tensor) -> Tensor:
         """Column sums over this rank's real rows (padding rows carry zero gradient by

@@ -64,6 +64,9 @@ def make_graph(kind):
         return g, torch.arange(30000) < g.n_vocab
     if kind == "wordoc_allhubs":
         return synth.word_doc_graph(400, 4000, seed=12, n_classes=5), None
+    if kind == "powerlaw_allhubs":    # sparse enough that a rank's rows reference only part of the other ranks' nodes
+        g = synth.power_law_graph(900, 2400, seed=15, n_classes=5, features="sparse_identity")
+        return g, None
     if kind in ("asym", "asym_keep_loops", "asym_raw"):
         g = synth.random_graph(300, 2500, seed=13, self_loops=7, duplicates=11)
         g.y = torch.randint(0, 5, (300,), generator=torch.Generator().manual_seed(1))
@@ -122,6 +125,8 @@ def check(kind, device="cpu"):
         ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N) + b
         got = sg.gather_rows(sg.spmm(sg.scatter_rows(x), b, transpose=transpose))
         assert rel_err(got, ref) < 1e-5, (kind, transpose, rel_err(got, ref))
+
+    check_exchange_forms(sg, x, b)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
     torch.manual_seed(3)
@@ -198,6 +203,39 @@ def check(kind, device="cpu"):
         sg.spmm = real_spmm
 
 
+def check_exchange_forms(sg, x_full, bias):
+    """Every form of the exchange gives the same distributed SpMM: the pairwise and the halo form (index lists,
+    pruned reduce-scatter), with A_r in one or several row chunks, are bit-for-bit alike (both add the ranks' partial
+    rows in rank order); RCCL's / gloo's reduce-scatter may add in another order (1e-6)."""
+    x_l = sg.scatter_rows(x_full.to(sg.device))
+    bias = bias.to(sg.device)
+    keep = (sg.exchange, sg.rs_chunks)
+    try:
+        for transpose in (False, True):
+            sg.exchange = "p2p"
+            sg.set_rs_chunks(1)
+            base = sg.spmm(x_l, bias, transpose=transpose).clone()
+            for form in sg.EXCHANGES:
+                for K in (1, 3):
+                    sg.exchange = form
+                    sg.set_rs_chunks(K)
+                    got = sg.spmm(x_l, bias, transpose=transpose)
+                    if form == "collective":
+                        assert rel_err(got.cpu(), base.cpu()) < 1e-6, (form, K, transpose)
+                    else:
+                        assert torch.equal(got, base), (form, K, transpose, rel_err(got.cpu(), base.cpu()))
+        # the halo lists prune: never more rows than the whole block, and the reduce side only rows A_r touches
+        rows = sg.exchange_rows()
+        assert rows["gather_halo"] <= rows["gather_all"]
+        if sg.num_nodes == 900:                # the sparse power-law graph: the halo is a fraction of the operand
+            assert rows["gather_halo"] < 0.8 * rows["gather_all"], rows
+        if "reduce_halo" in rows:
+            assert rows["reduce_halo"] <= rows["reduce_all"]
+    finally:
+        sg.exchange = keep[0]
+        sg.set_rs_chunks(keep[1])
+
+
 def check_hip(kind, g, hubs, N, dev):
     """The same checks with the product engine (libtgcn.so) on a GPU; all ranks may share one card
     (gloo moves the collectives' payload through the host)."""
@@ -213,6 +251,7 @@ def check_hip(kind, g, hubs, N, dev):
         ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N) + b
         got = sg.gather_rows(sg.spmm(sg.scatter_rows(x.to(dev)), b.to(dev), transpose=transpose))
         assert rel_err(got.cpu(), ref) < 1e-5, (kind, transpose, rel_err(got.cpu(), ref))
+    check_exchange_forms(sg, x, b)
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)

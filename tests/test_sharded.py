@@ -77,3 +77,18 @@ def test_world3_pairwise_exchange(monkeypatch):
     """TGCN_EXCHANGE=p2p: the same hub exchange as batched send/recv + all-to-all with a local sum."""
     monkeypatch.setenv("TGCN_EXCHANGE", "p2p")            # inherited by the spawned ranks
     run(3, ["wordoc", "asym"])
+
+
+def test_world3_halo_exchange_with_chunked_reduce(monkeypatch):
+    """TGCN_EXCHANGE=halo + TGCN_RS_CHUNKS=2 through the whole model-level check: only referenced hub rows are
+    gathered, only touched partial rows are reduced, A_r runs in two row chunks."""
+    monkeypatch.setenv("TGCN_EXCHANGE", "halo")
+    monkeypatch.setenv("TGCN_RS_CHUNKS", "2")
+    run(3, ["wordoc", "asym"])
+
+
+def test_world4_graph_without_hub_structure_true_halo(monkeypatch):
+    """hubs=None (every node's rows may be needed anywhere, config c5's situation): the halo form sends the rows the
+    receiving rank's operator references instead of all-gathering the whole operand."""
+    monkeypatch.setenv("TGCN_EXCHANGE", "halo")
+    run(4, ["powerlaw_allhubs"])
