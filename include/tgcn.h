@@ -236,11 +236,15 @@ int tgcn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
 /* ---------------------------------------------------------------------------------------------
  * Tall-skinny fp32 GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32): the dense
  * `torch.matmul(x, self.weight)` of PyG-1.6.3 GCNConv.forward (reference call site models.py:20,
- * layers built at models.py:13,15) and its autograd.  N = number of nodes; k, n = layer widths <= 256
- * with k_pad * n_pad * 4 bytes <= 160 KB (the small operand lives in LDS).
+ * layers built at models.py:13,15) and its autograd.  N = number of nodes; k, n = layer widths, any value >= 1.
+ * The small operand lives in LDS: one launch when k_pad * n_pad * 4 bytes <= 160 KB (k_pad = k rounded up to 8,
+ * n_pad = n rounded up to 32; e.g. 200 x 64, 64 x 200), otherwise the product runs as column groups of <= 128 result
+ * columns and k chunks of <= 256 that accumulate into C (e.g. DBpedia's 219 classes at hidden width 200, flat_dbpedia.py:80:
+ * two groups) -- the tall operand is then read once per group.
  *   tgcn_gemm_nn   C[N,n] = A[N,k] @ B[k,n]        (XW  = H @ W)        A: lda % 4 == 0, 16-B aligned
  *   tgcn_gemm_nt   C[N,n] = A[N,k] @ B[n,k]^T      (dH  = dXW @ W^T)    A: lda % 4 == 0, 16-B aligned
- *   tgcn_gemm_tn   C[k,n] = A[N,k]^T @ G[N,n]      (dW  = H^T @ dXW)    n <= 128; deterministic
+ *   tgcn_gemm_tn   C[k,n] = A[N,k]^T @ G[N,n]      (dW  = H^T @ dXW)    deterministic; one launch covers <= 256 columns
+ *                                                                        of A x <= 128 of G, wider ones run in chunks
  */
 int tgcn_gemm_nn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                  int64_t N, int k, int n, tgcn_stream stream);
@@ -267,8 +271,8 @@ int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ld
                          int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
                          size_t workspace_bytes, tgcn_stream stream);
 /* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt / _tn for the
- * shapes of the GCN layers (nn: k = 200, n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64, contiguous
- * operands; + the _dropout / _colsum forms).  on != 0: every fp32 product is
+ * shapes of the GCN layers (nn: k = 200, 33 <= n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64,
+ * contiguous operands; + the _dropout forms and, for nt, the _colsum form).  Every other shape keeps the fp32 kernels.  on != 0: every fp32 product is
  * formed from an exact three-way bf16 split of both operands on the bf16 matrix cores (six partial products,
  * fp32 accumulation, dropped terms <= 2^-23 relative): fp32-accurate, NOT the fp32 FMA chain bit for bit, +-inf
  * operands give nan.  Default off (TGCN_GEMM_SPLIT=1 in the environment turns it on at load).  Returns the

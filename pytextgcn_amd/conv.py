@@ -159,6 +159,53 @@ def split_identity_block(x: Tensor):
     return rest
 
 
+# Sparse feature blocks that are NOT the identity -- the hierarchy block H of [I | H], or a general sparse x --
+# times a dense weight: the same CSR SpMM as the propagate step, on a rectangular operator built once per feature
+# tensor (tgcn_plan_create_coo with its transpose, for the weight gradient H^T @ dXW).
+_FEATURE_PLANS: dict = {}
+
+
+def _feature_plan(x: Tensor) -> GraphPlan:
+    hit = _FEATURE_PLANS.get(id(x))
+    if hit is not None and hit[0]() is x:
+        return hit[1]
+    xc = x if x.is_coalesced() else x.coalesce()
+    idx, val = xc.indices(), xc.values()
+    plan = GraphPlan.from_coo(idx[0], idx[1], val, x.size(0), x.size(1), with_transpose=True)
+    key = id(x)
+    _FEATURE_PLANS[key] = (weakref.ref(x, lambda _, k=key: _FEATURE_PLANS.pop(k, None)), plan)
+    return plan
+
+
+class _SparseTimesDense(torch.autograd.Function):
+    """x_sparse @ w and d w = x_sparse^T @ d out (the features carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, w: Tensor):
+        ctx.plan = plan
+        F = w.size(1)
+        F4 = (F + 3) & ~3
+        ctx.F = F
+        out = plan.spmm(_pad_cols(w.detach(), F4).contiguous())
+        return out if F4 == F else out[:, :F]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        F4 = (ctx.F + 3) & ~3
+        dw = ctx.plan.spmm(_pad_cols(grad_out, F4).contiguous(), transpose=True)
+        return None, dw if F4 == ctx.F else dw[:, :ctx.F]
+
+
+def sparse_times(x: Tensor, w: Tensor) -> Tensor:
+    """`x @ w` for a sparse COO feature matrix on the HIP SpMM (no torch.sparse.mm / vendor library)."""
+    if not x.is_cuda:
+        raise RuntimeError(f"pytextgcn_amd: sparse features live on {x.device}; the GCN path runs only on an AMD GPU "
+                           "through libtgcn.so (there is no CPU fallback)")
+    if w.dtype != torch.float32:
+        raise TypeError("sparse features times weight: float32 weights only (flat_amazon.py:85 casts the model)")
+    return _SparseTimesDense.apply(_feature_plan(x), w)
+
+
 def glorot_(t: Tensor) -> Tensor:
     a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
     with torch.no_grad():
@@ -226,7 +273,7 @@ class GCNConv(nn.Module):
             return w
         h = split_identity_block(x)
         n = x.size(0)
-        return w[:n] + torch.sparse.mm(h, w[n:]) if h is not None else torch.sparse.mm(x, w)
+        return w[:n] + sparse_times(h, w[n:]) if h is not None else sparse_times(x, w)
 
     def __getstate__(self):
         # th.save(gcn, ...) pickles the whole module (flat_amazon.py:128): cached activations and the

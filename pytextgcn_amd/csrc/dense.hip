@@ -28,7 +28,17 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxSmall = 256;  // k, n <= 256
+constexpr int kGroupCols = 128;  // widest column group of one launch (4 tiles of 32): k x 128 floats of LDS
+constexpr int kGroupK = 256;     // longest reduction of one launch: 256 x 128 x 4 B = 128 KB of the 160 KB LDS
+
+// Where one launch sits inside a product whose small operand exceeds the LDS (or the accumulator registers): widths
+// above 128 columns run as column groups, reductions above 256 as k chunks that accumulate into C.  Only the
+// dropout hash needs to know (it is a function of the GLOBAL element position).
+struct Place {
+    int col0;    // first result column of this launch
+    int k0;      // first index of the reduction
+    int accum;   // C += instead of C =
+};
 
 // Two workgroups per CU (a 256-register budget per lane) for the nt kernels with a masked result and / or column
 // sums: hipcc then keeps the accumulator tiles in the same register file as everything else instead of splitting
@@ -94,7 +104,8 @@ template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP, bool COLSUM = false>
 __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGCN_TALL_MIN_BLOCKS : 1) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
-                                                   int k, int n, const Drop drop, float *__restrict__ colpart) {
+                                                   int k, int n, const Drop drop, float *__restrict__ colpart,
+                                                   const Place place) {
     extern __shared__ float lds[];  // [kpad][npad] (+ [4][npad] with COLSUM)
     float csum[NT];
 #pragma unroll
@@ -130,6 +141,17 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        if (place.accum) {                     // a later k chunk: continue the sums the earlier launches left in C
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 32 * t + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    if (col < n && orow < N) acc[t][i] = C[orow * ldc + col];
+                }
+            }
+        }
         auto load_a = [&](int q) -> float4 {
             if (q >= nq) return make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (K8) {
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
                 if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
-                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(8 * q + 4 * half + s4), drop);
+                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(place.k0 + 8 * q + 4 * half + s4), drop);
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
-                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(8 * q + 4 * half + s4), drop);
+                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(place.k0 + 8 * q + 4 * half + s4), drop);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
         for (int t = 0; t < NT; ++t) {
             const int col = 32 * t + r;
             if (col < n) {
-                const uint32_t cterm = drop_col_term(col);
+                const uint32_t cterm = drop_col_term(place.col0 + col);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -497,7 +519,9 @@ template <int NT, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restrict__ A, int64_t lda,
                                                             const float *__restrict__ G, int64_t ldg,
                                                             int64_t N, int k, int n, int64_t rows_per_wg,
-                                                            float *__restrict__ partial, const Drop drop) {
+                                                            float *__restrict__ partial, const Drop drop, const int k0) {
+    // k0: global column of A's first column here (a product with more than 256 columns of A runs in chunks; the
+    // dropout hash is a function of the global position)
     uint32_t s_lo = 0, s_hi = 0;
     if constexpr (DROP) {
         const uint64_t sd = *drop.seed;
@@ -554,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
             float x0 = a0[buf][u], x1 = a1[buf][u];
             if constexpr (DROP) {
                 const uint32_t key = drop_row_key(s_lo, s_hi, stage_row[buf] + 2 * u);
-                x0 = drop_elem(x0, key, drop_col_term(ca0), drop);
-                x1 = drop_elem(x1, key, drop_col_term(ca1), drop);
+                x0 = drop_elem(x0, key, drop_col_term(k0 + ca0), drop);
+                x1 = drop_elem(x1, key, drop_col_term(k0 + ca1), drop);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -581,8 +605,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
         if constexpr (DROP) {
             const uint32_t key = drop_row_key(s_lo, s_hi, r_begin + r + half - back);
-            x0 = drop_elem(x0, key, drop_col_term(ca0), drop);
-            x1 = drop_elem(x1, key, drop_col_term(ca1), drop);
+            x0 = drop_elem(x0, key, drop_col_term(k0 + ca0), drop);
+            x1 = drop_elem(x1, key, drop_col_term(k0 + ca1), drop);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -788,9 +812,9 @@ int tn_blocks(int64_t N) {
 constexpr int kTallMaxGrid = 256 * 4 * 2;   // upper bound of the persistent grid (CUs x resident workgroups), sizes colpart
 
 template <bool TRANS_B, bool DROP, bool COLSUM = false>
-int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                int64_t N, int k, int n, const Drop drop, hipStream_t s, float *colpart = nullptr,
-                float *colsum = nullptr) {
+int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                    int64_t N, int k, int n, const Drop drop, hipStream_t s, float *colpart, float *colsum,
+                    const Place place) {
     const int nt = (n + 31) / 32;
     const int kpad = (k + 7) & ~7;
     const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(kpad) * (32 * nt) + (COLSUM ? 4 * 32 * nt : 0));
@@ -829,7 +853,7 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
             1, std::min<int64_t>({(n_blocks + 3) / 4, int64_t(n_cu) * per_cu, int64_t(kTallMaxGrid)}))); \
         grid_used = grid;                                                                         \
         k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
-                                                                                     drop, colpart); \
+                                                                                     drop, colpart, place); \
     } while (0)
 #define TGCN_TALL(NT)                                                                             \
     do {                                                                                          \
@@ -844,7 +868,8 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         if constexpr (COLSUM) return launch_colsum_final(colpart, grid_used, n, colsum, s);
         return TGCN_OK;
     };
-    if (g_gemm_split.load(std::memory_order_relaxed) != 0 && lda % 4 == 0) {
+    const bool whole = place.col0 == 0 && place.k0 == 0 && !place.accum;      // not a piece of a larger product
+    if (whole && g_gemm_split.load(std::memory_order_relaxed) != 0 && lda % 4 == 0) {
         // split-bf16 products for the two shapes of the GCN layers (everything else keeps the fp32 MFMA kernels)
 #define TGCN_SPLIT(NT, NQ_)                                                                                         \
     do {                                                                                                            \
@@ -867,11 +892,11 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
         }
 #undef TGCN_SPLIT
     }
-    if (!TRANS_B && k == 200 && nt == 2) {
+    if (whole && !TRANS_B && k == 200 && nt == 2) {
         TGCN_TALL_K(2, true, 25);
         return finish();
     }
-    if (TRANS_B && k == 64 && nt == 7) {
+    if (whole && TRANS_B && k == 64 && nt == 7) {
         TGCN_TALL_K(7, true, 8);
         return finish();
     }
@@ -890,10 +915,42 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
     return finish();
 }
 
+// The whole product: one launch when the small operand (k x n, padded) fits the LDS, otherwise column groups of
+// <= 128 result columns (the tall operand is read once per group: these shapes sit on the fp32 MFMA roof, not on
+// the HBM one) and, for reductions longer than 256, k chunks that accumulate into C.  A mask on the RESULT (nt
+// with dropout) and the column sums are the business of the last chunk alone.
+template <bool TRANS_B, bool DROP, bool COLSUM = false>
+int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                int64_t N, int k, int n, const Drop drop, hipStream_t s, float *colpart = nullptr,
+                float *colsum = nullptr) {
+    const int kpad = (k + 7) & ~7, npad = 32 * ((n + 31) / 32);
+    if (sizeof(float) * (size_t(kpad) * npad + (COLSUM ? 4 * npad : 0)) <= 160 * 1024)
+        return launch_tall_one<TRANS_B, DROP, COLSUM>(A, lda, B, ldb, C, ldc, N, k, n, drop, s, colpart, colsum,
+                                                      Place{0, 0, 0});
+    for (int j0 = 0; j0 < n; j0 += kGroupCols) {
+        const int ng = std::min(kGroupCols, n - j0);
+        const float *Bg = TRANS_B ? B + int64_t(j0) * ldb : B + j0;
+        for (int k0 = 0; k0 < k; k0 += kGroupK) {
+            const int kg = std::min(kGroupK, k - k0);
+            const bool last = k0 + kg >= k;
+            const float *Bc = TRANS_B ? Bg + k0 : Bg + int64_t(k0) * ldb;
+            const Place place{j0, k0, k0 > 0 ? 1 : 0};
+            if (TRANS_B && !last) {
+                TGCN_CHECK((launch_tall_one<TRANS_B, false, false>(A + k0, lda, Bc, ldb, C + j0, ldc, N, kg, ng, Drop{}, s,
+                                                                  nullptr, nullptr, place)));
+            } else {
+                TGCN_CHECK((launch_tall_one<TRANS_B, DROP, COLSUM>(
+                    A + k0, lda, Bc, ldb, C + j0, ldc, N, kg, ng, drop, s,
+                    colpart ? colpart + size_t(kTallMaxGrid) * j0 : nullptr, colsum ? colsum + j0 : nullptr, place)));
+            }
+        }
+    }
+    return TGCN_OK;
+}
+
 int check_common(const char *fn, const void *a, const void *b, const void *c, int64_t N, int k, int n) {
-    if (!a || !b || !c || N < 0 || k <= 0 || n <= 0 || k > kMaxSmall || n > kMaxSmall) {
-        set_error("%s: bad argument (N=%lld k=%d n=%d; widths must be in [1, %d])", fn, (long long)N, k, n,
-                  kMaxSmall);
+    if (!a || !b || !c || N < 0 || k <= 0 || n <= 0) {
+        set_error("%s: bad argument (N=%lld k=%d n=%d)", fn, (long long)N, k, n);
         return TGCN_E_INVALID;
     }
     return TGCN_OK;
@@ -1005,7 +1062,8 @@ int tgcn_gemm_nt_colsum(const float *A, int64_t lda, const float *B, int64_t ldb
 
 size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {
     if (N < 0 || k <= 0 || n <= 0) return 0;
-    const size_t mpad = 32 * ((k + 31) / 32), npad = 32 * ((n + 31) / 32);
+    // one launch's partial tiles (wider products reuse the region launch after launch)
+    const size_t mpad = 32 * ((std::min(k, tgcn::kGroupK) + 31) / 32), npad = 32 * ((std::min(n, tgcn::kGroupCols) + 31) / 32);
     return sizeof(float) * static_cast<size_t>(tgcn::tn_blocks(N)) * mpad * npad;
 }
 
@@ -1047,26 +1105,35 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
         TGCN_HIP_CHECK(hipGetLastError());
         return TGCN_OK;
     }
-#define TGCN_TN(NT)                                                                                          \
-    do {                                                                                                     \
-        if (drop)                                                                                            \
-            k_gemm_tn_partial<NT, true><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial, *drop); \
-        else                                                                                                 \
-            k_gemm_tn_partial<NT, false><<<nb, 256, 0, s>>>(A, lda, G, ldg, N, k, n, rows_per_wg, partial, Drop{}); \
+    // One launch covers <= 256 columns of A (8 M-tiles, two per wave) x <= 128 columns of G (4 accumulator tiles per
+    // M-tile); wider products run as several launches over column chunks of A and / or G, each followed by its
+    // reduction -- they share the workspace, in stream order.
+    for (int i0 = 0; i0 < k; i0 += kGroupK) {
+        const int kg = std::min(kGroupK, k - i0);
+        for (int j0 = 0; j0 < n; j0 += kGroupCols) {
+            const int ng = std::min(kGroupCols, n - j0);
+            const int ntg = (ng + 31) / 32, mtg = (kg + 31) / 32;
+            const float *Ag = A + i0, *Gg = G + j0;
+#define TGCN_TN(NT)                                                                                                   \
+    do {                                                                                                              \
+        if (drop)                                                                                                     \
+            k_gemm_tn_partial<NT, true><<<nb, 256, 0, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rows_per_wg, partial, *drop, i0); \
+        else                                                                                                          \
+            k_gemm_tn_partial<NT, false><<<nb, 256, 0, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rows_per_wg, partial, Drop{}, i0); \
     } while (0)
-    switch (nt) {
-        case 1: TGCN_TN(1); break;
-        case 2: TGCN_TN(2); break;
-        case 3: TGCN_TN(3); break;
-        case 4: TGCN_TN(4); break;
-        default:
-            set_error("%s: n = %d > 128 is not instantiated (use tgcn_gemm_tn with the roles of A and G swapped)", fn, n);
-            return TGCN_E_INVALID;
-    }
+            switch (ntg) {
+                case 1: TGCN_TN(1); break;
+                case 2: TGCN_TN(2); break;
+                case 3: TGCN_TN(3); break;
+                default: TGCN_TN(4); break;
+            }
 #undef TGCN_TN
-    TGCN_HIP_CHECK(hipGetLastError());
-    k_gemm_tn_reduce<<<(k * n + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mt, 32 * nt, k, n, C, ldc);
-    TGCN_HIP_CHECK(hipGetLastError());
+            TGCN_HIP_CHECK(hipGetLastError());
+            k_gemm_tn_reduce<<<(kg * ng + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mtg, 32 * ntg, kg, ng,
+                                                                 C + int64_t(i0) * ldc + j0, ldc);
+            TGCN_HIP_CHECK(hipGetLastError());
+        }
+    }
     return TGCN_OK;
 }
 

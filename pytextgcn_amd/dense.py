@@ -1,7 +1,8 @@
 """Dense X @ W of the GCN layers on the fp32 matrix cores (libtgcn.so `tgcn_gemm_*`,
 pytextgcn_amd/csrc/dense.hip): replaces `torch.matmul(x, self.weight)` of PyG-1.6.3
 GCNConv.forward (reference call site textgcn/lib/models.py:20) and its autograd for tall-skinny
-shapes -- millions of rows, layer widths <= 256."""
+shapes -- millions of rows, layer widths of a few hundred (one launch while the small operand fits the
+LDS, column groups / k chunks beyond: DBpedia's 219 classes at hidden width 200 take two groups)."""
 from __future__ import annotations
 
 import torch
@@ -9,8 +10,6 @@ from torch import Tensor
 
 from . import _lib
 from .plan import _stream_ptr
-
-_MAX = 256
 
 
 def enable_split_gemms(on: bool = True) -> bool:
@@ -20,13 +19,16 @@ def enable_split_gemms(on: bool = True) -> bool:
     return bool(_lib.load().tgcn_set_gemm_split(1 if on else 0))
 
 
-def supported(x: Tensor, w: Tensor) -> bool:
-    k, n = w.shape
-    kpad, npad = (k + 7) & ~7, 32 * ((n + 31) // 32)
-    kpad_t, npad_t = (n + 7) & ~7, 32 * ((k + 31) // 32)            # the backward's nt product
-    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
-            and k <= _MAX and n <= 128 and kpad * npad * 4 <= 160 * 1024
-            and kpad_t * npad_t * 4 <= 160 * 1024)
+def _require(x: Tensor, w: Tensor) -> None:
+    """The dense layers run on libtgcn.so only: anything else is an error, never a silent vendor fallback."""
+    if not x.is_cuda or not w.is_cuda:
+        raise RuntimeError(f"pytextgcn_amd: dense x @ W needs both operands on an AMD GPU (x on {x.device}, W on "
+                           f"{w.device}); there is no CPU fallback")
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or x.dim() != 2 or w.dim() != 2:
+        raise TypeError(f"pytextgcn_amd: dense x @ W takes 2-D float32 operands, got {x.dtype} {tuple(x.shape)} and "
+                        f"{w.dtype} {tuple(w.shape)} (the reference casts the model with .float(), flat_amazon.py:85)")
+    if x.size(1) != w.size(0) or w.size(0) == 0 or w.size(1) == 0:
+        raise ValueError(f"x @ W: shapes {tuple(x.shape)} and {tuple(w.shape)} do not fit")
 
 
 def _rowmajor4(t: Tensor) -> Tensor:
@@ -150,16 +152,14 @@ def new_seed(device) -> Tensor:
 
 def xw_dropout(x: Tensor, w: Tensor, p: float, seed: Tensor = None) -> Tensor:
     """dropout(x, p) @ w (training-mode inverted dropout, textgcn/lib/models.py:23 followed by the next
-    layer's x @ W) as ONE pass over x.  Falls back to torch's dropout + matmul for unsupported shapes."""
+    layer's x @ W) as ONE pass over x."""
     if p <= 0.0:
         return xw(x, w)
-    if supported(x, w):
-        return _XWDropout.apply(x, w, float(p), new_seed(x.device) if seed is None else seed)
-    return torch.matmul(torch.nn.functional.dropout(x, p, True), w)
+    _require(x, w)
+    return _XWDropout.apply(x, w, float(p), new_seed(x.device) if seed is None else seed)
 
 
 def xw(x: Tensor, w: Tensor) -> Tensor:
-    """x @ w with gradients, on the hand-written MFMA kernels when the shape is tall-skinny."""
-    if supported(x, w):
-        return _XW.apply(x, w)
-    return torch.matmul(x, w)
+    """x @ w with gradients, on the hand-written MFMA kernels."""
+    _require(x, w)
+    return _XW.apply(x, w)

@@ -739,7 +739,7 @@ class ShardedGCN(nn.Module):
                 xw = eng.xw_dropout(x, self.weights[i], float(self.dropout))
             else:
                 x = nn.functional.dropout(x, p=self.dropout, training=self.training)
-                xw = eng.xw(x, self.weights[i]) if hasattr(eng, "xw") else torch.matmul(x, self.weights[i])
+                xw = eng.xw(x, self.weights[i])
             x = sharded_propagate(self.sg, xw, self.biases[i])
         return x
 

@@ -903,7 +903,10 @@ def test_mfma_gemm_identity_with_asymmetric_operand(cuda):
 
 
 @pytest.mark.parametrize("N,k,n", [(1, 1, 1), (31, 7, 3), (33, 200, 64), (1000, 64, 64), (4097, 200, 10),
-                                   (5000, 256, 128), (70000, 200, 64), (2500, 100, 5)])
+                                   (5000, 256, 128), (70000, 200, 64), (2500, 100, 5),
+                                   # beyond one LDS image of the small operand: column groups / k chunks (c3: 219 classes)
+                                   (50_001, 200, 219), (50_001, 219, 200), (20_000, 256, 256), (3000, 300, 8),
+                                   (3000, 8, 300), (2000, 520, 260), (1000, 129, 129)])
 def test_mfma_gemms_match_float64(cuda, N, k, n):
     from pytextgcn_amd import dense
     gen = torch.Generator().manual_seed(N + k + n)
@@ -1018,13 +1021,78 @@ def test_dense_layer_autograd_uses_the_mfma_kernels(cuda):
     go = torch.randn(3000, 64, generator=gen)
     (x @ w).backward(go)
     xd, wd = x.detach().to(cuda).requires_grad_(), w.detach().to(cuda).requires_grad_()
-    assert dense.supported(xd, wd)
     out = dense.xw(xd, wd)
     out.backward(go.to(cuda))
     assert rel_err(out, x @ w) < TOL and rel_err(xd.grad, x.grad) < TOL and rel_err(wd.grad, w.grad) < TOL
-    wide = torch.randn(10, 300, device=cuda)                               # outside the kernels' range
-    assert not dense.supported(wide, torch.randn(300, 8, device=cuda))
+    wide = torch.randn(10, 300, device=cuda)                               # a reduction longer than one LDS image
     assert rel_err(dense.xw(wide, torch.ones(300, 8, device=cuda)), wide.cpu() @ torch.ones(300, 8)) < TOL
+    # no vendor fallback: anything the kernels do not take is an error
+    with pytest.raises(TypeError):
+        dense.xw(wide.double(), torch.ones(300, 8, device=cuda, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dense.xw(wide.cpu(), torch.ones(300, 8))
+
+
+@pytest.mark.parametrize("N,k,n,p", [(30_001, 200, 219, 0.5), (20_000, 219, 200, 0.3), (5000, 300, 260, 0.5)])
+def test_fused_dropout_products_wider_than_one_lds_image(cuda, N, k, n, p):
+    """dropout(x) @ w and its two gradients where the small operand does not fit the LDS (c3: hidden 200, 219 classes):
+    the column groups / k chunks must regenerate the SAME mask (the hash is a function of the global position), and
+    the column sums of the nt epilogue must cover every group."""
+    from pytextgcn_amd import dense, plan as plan_mod
+    gen = torch.Generator().manual_seed(N + k)
+    x = torch.randn(N, k, generator=gen).to(cuda)
+    w = (torch.randn(k, n, generator=gen) * 0.1).to(cuda)
+    g = torch.randn(N, n, generator=gen).to(cuda)
+    seed = dense.new_seed(cuda)
+    # the mask itself: dropout(ones) @ identity-like probe -> read it back through the nn product column by column
+    ones = torch.ones(N, k, device=cuda)
+    eye = torch.eye(k, device=cuda)
+    mask = dense.gemm_nn(ones, eye, p, seed)                      # [N, k] = the kept / scaled pattern of the A operand
+    keep = (mask != 0)
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+    assert torch.allclose(mask[keep], torch.full((1,), 1 / (1 - p), device=cuda))
+    xd = (x * mask).double()
+    assert rel_err(dense.gemm_nn(x, w, p, seed), (xd @ w.double()).float()) < TOL
+    assert rel_err(dense.gemm_tn(x, g, p, seed), (xd.t() @ g.double()).float()) < TOL
+    dx = dense.gemm_nt(g, w, p, seed, note_colsums=True)          # mask over the [N, k] result
+    ref = (g.double() @ w.double().t()) * mask.double()
+    assert rel_err(dx, ref.float()) < TOL
+    sums = plan_mod._known_colsum(dx)
+    assert sums is not None
+    assert ((sums.double() - dx.double().sum(0)).abs().max() / dx.double().sum(0).abs().max()).item() < 2e-5
+
+
+def test_config_c3_sized_layer_two_runs_on_the_hand_written_kernels(cuda, monkeypatch):
+    """GCN(N, 219, n_hidden_gcn=200) -- DBpedia l3's class count at BASELINE's hidden width (flat_dbpedia.py:80) --
+    forward and backward against float64, with torch.matmul made to fail: no product of the model may reach
+    rocBLAS."""
+    N, C, h = 60_000, 219, 200
+    g = synth.word_doc_graph(N, 1_200_000, seed=44, device=cuda, n_classes=C, vocab_frac=0.03, doc_word_share=0.9)
+    torch.manual_seed(1)
+    model = pkg.GCN(N, C, n_hidden_gcn=h, dropout=0.0).to(cuda).float()
+
+    def no_vendor_gemm(*a, **kw):
+        raise AssertionError("torch.matmul was called on the GCN path")
+    real = torch.matmul
+    monkeypatch.setattr(torch, "matmul", no_vendor_gemm)
+    out = model(g)
+    go = torch.randn(N, C, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    out.backward(go)
+    monkeypatch.setattr(torch, "matmul", real)
+    # float64 reference of the same network from the plan's own operator
+    plan = model.layers[0].plan(g.x, g.edge_index, g.edge_attr)
+    rp, col, val = plan.export_csr()
+    M = torch.sparse_csr_tensor(rp.long(), col.long(), val.double(), (N, N))
+    W1, b1 = model.layers[0].weight.detach().double(), model.layers[0].bias.detach().double()
+    W2, b2 = model.layers[1].weight.detach().double(), model.layers[1].bias.detach().double()
+    H1 = M @ W1 + b1
+    ref = M @ (H1 @ W2) + b2
+    assert rel_err(out.detach(), ref.float()) < TOL
+    dXW2 = M.t().to_sparse_csr() @ go.double() if not plan.symmetric else M @ go.double()
+    assert rel_err(model.layers[1].weight.grad, (H1.t() @ dXW2).float()) < TOL
+    dH1 = dXW2 @ W2.t()
+    assert rel_err(model.layers[0].bias.grad, dH1.sum(0).float()) < 2e-5
+    assert rel_err(model.layers[0].weight.grad, (M @ dH1).float()) < TOL
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1364,7 +1432,17 @@ def test_graphed_training_matches_eager_training(cuda):
 
 def test_three_layer_gcn_and_general_sparse_features(cuda):
     """n_gcn = 3 (input -> h -> h -> classes, models.py:11-15) and a sparse feature matrix that is NOT
-    the identity (falls back to torch.sparse.mm for X @ W1)."""
+    the identity: X @ W1 and its weight gradient run on the HIP SpMM over a rectangular feature plan
+    (conv.sparse_times), not on torch.sparse.mm."""
+    real_spmm = torch.sparse.mm
+    torch.sparse.mm = None                                  # the model must not reach it
+    try:
+        _three_layer_general_sparse(cuda)
+    finally:
+        torch.sparse.mm = real_spmm
+
+
+def _three_layer_general_sparse(cuda):
     N, Fin, C = 1500, 90, 7
     g = synth.word_doc_graph(N, 18000, seed=33, n_classes=C)
     gen = torch.Generator().manual_seed(3)

@@ -96,7 +96,8 @@ def test_fused_training_helpers_refuse_cpu_tensors():
         optim.Adam([p]).step()
     with pytest.raises(ValueError):
         optim.Adam([p], lr=-1.0)
-    assert not dense.supported(torch.zeros(4, 8), torch.zeros(8, 2))           # CPU tensors: torch.matmul
+    with pytest.raises(RuntimeError, match="no CPU fallback"):                 # no vendor / CPU matmul behind the layers
+        dense.xw(torch.zeros(4, 8), torch.zeros(8, 2))
     if not torch.cuda.is_available():
         import numpy as np
         with pytest.raises(RuntimeError, match="no CPU fallback"):
