@@ -819,7 +819,7 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
     const int kpad = (k + 7) & ~7;
     const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(kpad) * (32 * nt) + (COLSUM ? 4 * 32 * nt : 0));
     int grid_used = 0;
-    if (lds_bytes > 160 * 1024) {
+    if (lds_bytes > 160 * 1024 || nt > 8) {
         set_error("tgcn_gemm: the small operand (%d x %d) does not fit the 160 KB LDS", k, n);
         return TGCN_E_INVALID;
     }
@@ -924,7 +924,7 @@ int launch_tall(const float *A, int64_t lda, const float *B, int64_t ldb, float 
                 int64_t N, int k, int n, const Drop drop, hipStream_t s, float *colpart = nullptr,
                 float *colsum = nullptr) {
     const int kpad = (k + 7) & ~7, npad = 32 * ((n + 31) / 32);
-    if (sizeof(float) * (size_t(kpad) * npad + (COLSUM ? 4 * npad : 0)) <= 160 * 1024)
+    if (npad <= 256 && sizeof(float) * (size_t(kpad) * npad + (COLSUM ? 4 * npad : 0)) <= 160 * 1024)
         return launch_tall_one<TRANS_B, DROP, COLSUM>(A, lda, B, ldb, C, ldc, N, k, n, drop, s, colpart, colsum,
                                                       Place{0, 0, 0});
     for (int j0 = 0; j0 < n; j0 += kGroupCols) {

@@ -23,6 +23,44 @@ def rel_err(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
+def row_rel_err(a, b):
+    """max over rows r of ||a_r - b_r||_inf / ||b_r||_inf: the global max-norm of `rel_err` lets a light row be
+    wrong by the heaviest row's magnitude; this one holds every row to its own scale (all-zero rows of b must be
+    zero in a)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    num, den = (a - b).abs().max(1).values, b.abs().max(1).values
+    if bool((den == 0).any()):
+        assert float(num[den == 0].max()) == 0.0
+    ok = den > 0
+    return float((num[ok] / den[ok]).max()) if bool(ok.any()) else 0.0
+
+
+def _report(key, **values):
+    """Numbers a reader of DESIGN.md section 2.2 wants to see (who is how far from the float64 truth): appended to
+    gpurun_out/parity_report.jsonl when that directory exists.  Never part of an assertion."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"case": key, **values}) + "\n")
+
+
+def _truth_normalized_coo(ei, w, N):
+    """FLOAT64 ground truth of gcn_norm for a graph without input self loops (the synthetic c2 / c4 / c5 graphs):
+    degrees (incl. the added loop of weight 1) summed in float64 on the host, deg^-1/2 and the products in
+    float64.  (target, source, w_hat) in PyG's edge order: the edges, then one loop per node -- the order of
+    oracle/gcn_oracle.py `normalized_coo`, so the two can be compared entry by entry."""
+    ei, w = ei.cpu(), w.cpu().double()
+    assert bool((ei[0] != ei[1]).all())
+    deg = torch.ones(N, dtype=torch.float64).index_add_(0, ei[1], w)
+    dis = deg.pow(-0.5)
+    loops = torch.arange(N)
+    tgt, src = torch.cat([ei[1], loops]), torch.cat([ei[0], loops])
+    return tgt, src, torch.cat([w, torch.ones(N, dtype=torch.float64)]) * dis[src] * dis[tgt]
+
+
 def oracle_spmm(ei, w, n, x, bias=None, transpose=False, add_self_loops=True, normalize=True):
     ei, w = ei.cpu(), None if w is None else w.cpu()
     if normalize:
@@ -418,9 +456,21 @@ def test_config_c2_against_csr_oracle(cuda):
     x = torch.randn(N, F, device=cuda)
     b = torch.randn(F, device=cuda)
     rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N)
-    assert rel_err(plan.spmm(x, b), csr_oracle.csr_spmm(rp, c, v, x.cpu(), b.cpu(), acc64=True)) < TOL
+    got, want = plan.spmm(x, b), csr_oracle.csr_spmm(rp, c, v, x.cpu(), b.cpu(), acc64=True)
+    assert rel_err(got, want) < TOL
+    # row by row the oracle's own fp32 normalisation is the looser side (its heavy rows carry a sequentially
+    # summed degree): 5e-5 here; the same rows against the float64 truth are held to 1e-5 below
+    assert row_rel_err(got, want) < 5e-5
     rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N, transpose=True)
-    assert rel_err(plan.spmm(x, transpose=True), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)) < TOL
+    got_t, want_t = plan.spmm(x, transpose=True), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)
+    assert rel_err(got_t, want_t) < TOL and row_rel_err(got_t, want_t) < 5e-5
+    # float64 ground truth: every row of M @ X + b to 1e-5 of its own scale
+    tgt, src, w64 = _truth_normalized_coo(g.edge_index, g.edge_attr, N)
+    truth = torch.zeros(N, F, dtype=torch.float64).index_add_(0, tgt, w64.unsqueeze(1) * x.cpu().double()[src])
+    truth += b.cpu().double()
+    e_plan, e_oracle = row_rel_err(got, truth), row_rel_err(want, truth)
+    _report("c2_rows", plan_vs_float64_row_relative=e_plan, fp32_oracle_vs_float64_row_relative=e_oracle)
+    assert e_plan < TOL, (e_plan, e_oracle)
 
 
 def test_config_c4_full_size_properties_and_sampled_rows(cuda):
@@ -452,7 +502,7 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
     for r in sample.tolist():
         s, e = rp[r].item(), rp[r + 1].item()
         ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
-        assert rel_err(mx[r], ref.float()) < TOL, r
+        assert rel_err(mx[r], ref.float()) < TOL, r          # one row: this IS the row-relative error
     del rows, rowsum
 
 
@@ -472,15 +522,41 @@ def _oracle_csr(ei, w, N, rows=None):
     return rp, src[order].to(torch.int32), nw[order]
 
 
-def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref):
+def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=None, case=None):
     """Index arrays bit-exact; weights within 2e-6 of the largest one (the 1-ulp association difference of
-    DESIGN.md section 1 plus the oracle's sequential fp32 degree sums) and, entry by entry, within 1e-3
-    relative (a hub row's degree is a sequential fp32 sum of ~10^6 terms in the oracle)."""
+    DESIGN.md section 1 plus the oracle's sequential fp32 degree sums) and, entry by entry, within 5e-5 relative
+    of the fp32 ORACLE.  That per-entry slack is the oracle's, not the plan's: with `truth` (the float64 weights in
+    the same order) the plan must be within 2e-6 of the truth entry by entry, and the oracle's own distance from it
+    -- ~2.6e-5 on the rows of the heaviest word nodes, whose degree the reference formulation sums sequentially
+    in fp32 over ~10^6 terms -- is measured and reported."""
     assert torch.equal(rp.cpu().long(), rp_ref)
     assert torch.equal(col.cpu(), col_ref)
     v, vr = val.cpu().double(), val_ref.double()
     assert (v - vr).abs().max().item() <= 2e-6 * vr.abs().max().item()
-    assert bool(((v - vr).abs() <= 1e-3 * vr.abs() + 1e-30).all())
+    assert bool(((v - vr).abs() <= 5e-5 * vr.abs() + 1e-30).all())
+    if truth is not None:
+        plan_err = float(((v - truth).abs() / truth).max())
+        oracle_err = float(((vr - truth).abs() / truth).max())
+        _report(case or "csr", plan_vs_float64_per_entry=plan_err, fp32_oracle_vs_float64_per_entry=oracle_err)
+        assert plan_err <= 2e-6, (plan_err, oracle_err)
+
+
+def _check_heaviest_rows_against_truth(plan, N, tgt, src, w64, y, x, bias, n_rows=8, case=None):
+    """SpMM rows of the `n_rows` heaviest nodes against the float64 ground truth (float64 weights, float64 sums):
+    1e-5 ROW-relative -- these are the rows a global max-norm and the fp32 oracle are least able to judge."""
+    cnt = torch.bincount(tgt, minlength=N)
+    heavy = cnt.topk(n_rows).indices
+    xc = x.cpu().double()
+    worst = 0.0
+    for r in heavy.tolist():
+        sel = tgt == r
+        want = (w64[sel].unsqueeze(1) * xc[src[sel]]).sum(0)
+        if bias is not None:
+            want = want + bias.cpu().double()
+        e = row_rel_err(y[r:r + 1], want.unsqueeze(0))
+        worst = max(worst, e)
+        assert e < TOL, (r, int(cnt[r]), e)
+    _report(case or "heavy_rows", heaviest_rows_vs_float64_row_relative=worst, degrees=cnt[heavy].tolist())
 
 
 def test_config_c4_dense_and_loss_kernels_at_full_size(cuda):
@@ -569,16 +645,24 @@ def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
     assert plan.stats()["hot_rows"] > 0                         # the benchmark configuration of the kernels
     rp_ref, col_ref, val_ref = _oracle_csr(g.edge_index, g.edge_attr, N)
     rp, col, val = plan.export_csr()
-    _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref)
-    del rp, col, val
+    # which side of the heavy-row discrepancy is off: both against float64 (degrees summed in float64 on the host)
+    tgt, src, w64 = _truth_normalized_coo(g.edge_index, g.edge_attr, N)
+    order = torch.argsort(tgt * N + src, stable=True)
+    _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=w64[order], case="c4_weights")
+    del rp, col, val, order
     R = 60_000
     gen = torch.Generator(device=cuda).manual_seed(2)
     x = torch.randn(N, F, device=cuda, generator=gen)
     b = torch.randn(F, device=cuda, generator=gen)
-    out = plan.spmm(x, b)[:R].cpu()
+    full = plan.spmm(x, b)
+    _check_heaviest_rows_against_truth(plan, N, tgt, src, w64, full, x, b, case="c4_heaviest_rows")
+    del tgt, src, w64
+    out = full[:R].cpu()
+    del full
     nn_ = rp_ref[R].item()
     ref = csr_oracle.csr_spmm(rp_ref[:R + 1], col_ref[:nn_], val_ref[:nn_], x.cpu(), b.cpu(), acc64=True)
     assert rel_err(out, ref) < TOL
+    assert row_rel_err(out, ref) < 5e-5       # per row against the fp32 oracle (whose heavy rows are 2.6e-5 off the truth)
     # the transposed path reuses the same block (M is bitwise symmetric): same rows, same oracle
     out_t = plan.spmm(x, None, transpose=True)[:R].cpu()
     assert rel_err(out_t, ref - b.cpu()) < TOL
@@ -1149,17 +1233,18 @@ def test_config_c5_power_law_graph_h256(cuda):
     ei_cpu, w_cpu = g.edge_index.cpu(), g.edge_attr.cpu()
     del g
     tgt, src, nw = O.normalized_coo(ei_cpu, w_cpu, N)
+    _, _, w64 = _truth_normalized_coo(ei_cpu, w_cpu, N)          # same (edges, loops) order as the oracle's
     del ei_cpu, w_cpu
-    heavy = deg.topk(6).indices.cpu()
+    heavy = deg.topk(8).indices.cpu()
     pick = (tgt < R) | torch.isin(tgt, heavy)
-    tgt, src, nw = tgt[pick], src[pick], nw[pick]
+    tgt, src, nw, w64 = tgt[pick], src[pick], nw[pick], w64[pick]
     order = torch.argsort(tgt * N + src, stable=True)
-    tgt, src, nw = tgt[order], src[order].to(torch.int32), nw[order]
+    tgt, src, nw, w64 = tgt[order], src[order].to(torch.int32), nw[order], w64[order]
     nb = int((tgt < R).sum())
     rp_ref = torch.zeros(R + 1, dtype=torch.int64)
     rp_ref[1:] = torch.bincount(tgt[:nb], minlength=R).cumsum(0)
     e_r = rp[R].item()
-    _assert_csr_equal(rp[:R + 1], col[:e_r], val[:e_r], rp_ref, src[:nb], nw[:nb])
+    _assert_csr_equal(rp[:R + 1], col[:e_r], val[:e_r], rp_ref, src[:nb], nw[:nb], truth=w64[:nb], case="c5_weights")
     ref = csr_oracle.csr_spmm(rp_ref, src[:nb], nw[:nb], x.cpu(), acc64=True)
     assert rel_err(y[:R], ref) < TOL
     xc = x.cpu()
@@ -1171,10 +1256,17 @@ def test_config_c5_power_law_graph_h256(cuda):
         assert torch.equal(col[s:e].cpu(), src[sel])
         # a heavy row's weights all carry the factor deg[r]^-1/2, and the oracle (like the reference's
         # scatter_add on the CPU) sums deg[r] sequentially in fp32 over ~10^5..10^6 terms: that sum, not the
-        # plan's pairwise one, is off by ~sqrt(n) ulp -- hence 1e-4 here instead of 2e-6 / 1e-5
-        assert (val[s:e].cpu().double() - nw[sel].double()).abs().max().item() <= 1e-4 * nw[sel].abs().max().item()
-        want = (nw[sel].double().unsqueeze(1) * xc[src[sel].long()].double()).sum(0)
-        assert rel_err(y[r], want.float()) < 1e-4, r
+        # plan's, is the one that is off (measured against float64 and reported) -- so the plan is held to the
+        # FLOAT64 truth at 2e-6 per weight / 1e-5 per row, and to the fp32 oracle only at the oracle's own accuracy
+        v_plan, v_true = val[s:e].cpu().double(), w64[sel]
+        plan_err = float(((v_plan - v_true).abs() / v_true).max())
+        oracle_err = float(((nw[sel].double() - v_true).abs() / v_true).max())
+        _report("c5_heavy_row_weights", row=r, degree=int(sel.sum()), plan_vs_float64=plan_err,
+                fp32_oracle_vs_float64=oracle_err)
+        assert plan_err <= 2e-6, (r, plan_err, oracle_err)
+        assert float(((v_plan - nw[sel].double()).abs() / nw[sel].double()).max()) <= 5e-5
+        want = (v_true.unsqueeze(1) * xc[src[sel].long()].double()).sum(0)
+        assert rel_err(y[r], want.float()) < TOL, r
     del tgt, src, nw, xc, ref
     rows = torch.cat([deg.topk(6).indices, torch.randint(0, N, (150,), device=cuda, generator=gen)]).tolist()
     for r in rows:
@@ -1434,15 +1526,6 @@ def test_three_layer_gcn_and_general_sparse_features(cuda):
     """n_gcn = 3 (input -> h -> h -> classes, models.py:11-15) and a sparse feature matrix that is NOT
     the identity: X @ W1 and its weight gradient run on the HIP SpMM over a rectangular feature plan
     (conv.sparse_times), not on torch.sparse.mm."""
-    real_spmm = torch.sparse.mm
-    torch.sparse.mm = None                                  # the model must not reach it
-    try:
-        _three_layer_general_sparse(cuda)
-    finally:
-        torch.sparse.mm = real_spmm
-
-
-def _three_layer_general_sparse(cuda):
     N, Fin, C = 1500, 90, 7
     g = synth.word_doc_graph(N, 18000, seed=33, n_classes=C)
     gen = torch.Generator().manual_seed(3)
@@ -1454,11 +1537,17 @@ def _three_layer_general_sparse(cuda):
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(cuda).float()
     gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
-    lo_r, lo_m = ref(g), mine(gd)
-    assert rel_err(lo_m, lo_r) < TOL
     crit = torch.nn.CrossEntropyLoss()
+    lo_r = ref(g)
     crit(lo_r[g.train_mask], g.y[g.train_mask]).backward()
-    crit(lo_m[gd.train_mask], gd.y[gd.train_mask]).backward()
+    real_spmm = torch.sparse.mm
+    torch.sparse.mm = None                                  # the product must not reach it (the oracle above does)
+    try:
+        lo_m = mine(gd)
+        crit(lo_m[gd.train_mask], gd.y[gd.train_mask]).backward()
+    finally:
+        torch.sparse.mm = real_spmm
+    assert rel_err(lo_m, lo_r) < TOL
     for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
         assert rel_err(pm.grad, pr.grad) < 5 * TOL, k
 
