@@ -6,6 +6,7 @@ pytextgcn_amd/lib/libtgcn.so is git-ignored but travels to the GPU box with the 
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -34,6 +35,34 @@ def _stale() -> bool:
     return _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
+# Kernels that feed their operand through an INLINE-ASM load ring with hand-counted s_waitcnt (dense.hip: the fully
+# unrolled k_gemm_tall<.., NQ > 0, ..> and k_gemm_tall_split): the compiler's wait-count pass does not know those
+# registers are pending, so a spill or a scratch copy of a ring register between issue and wait would read stale data
+# without any diagnostic.  The build therefore FAILS when one of them uses scratch memory or spills vector registers
+# (hipcc -Rpass-analysis=kernel-resource-usage).
+_RING_KERNEL = re.compile(r"(k_gemm_tall_split|11k_gemm_tallILi\d+ELb[01]ELb[01]ELi[1-9]\d*E)")
+
+
+def check_asm_ring_kernels(remarks: str) -> None:
+    blocks = re.split(r"remark: Function Name: ", remarks)[1:]
+    seen, bad = 0, []
+    for b in blocks:
+        name = b.split()[0]
+        if not _RING_KERNEL.search(name):
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        if scratch or vspill:
+            bad.append(f"{name}: scratch {scratch} B/lane, {vspill} VGPRs spilled")
+    if seen == 0:
+        raise RuntimeError("build check: no kernel-resource-usage remarks for the asm-ring kernels of dense.hip "
+                           "(did the kernel names change?)")
+    if bad:
+        raise RuntimeError("build check: kernels with an inline-asm load ring must not spill (stale ring registers):\n  "
+                           + "\n  ".join(bad))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile what is newer than its object file (one hipcc process per stale source, run side by side),
     then link.  Returns the library path."""
@@ -53,6 +82,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(obj, [src] + HEADERS):
             tmp = obj + ".tmp%d" % os.getpid()
             cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", tmp]
+            if s == "dense.hip":
+                cmd.append("-Rpass-analysis=kernel-resource-usage")
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             jobs.append((s, obj, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -64,6 +95,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if os.path.exists(tmp):
                 os.remove(tmp)
         else:
+            if s == "dense.hip":
+                try:
+                    check_asm_ring_kernels(out)
+                except RuntimeError as e:
+                    failed.append(str(e))
+                    os.remove(tmp)
+                    continue
             os.replace(tmp, obj)
     if failed:
         raise RuntimeError("hipcc failed building libtgcn.so:\n" + "\n".join(failed))

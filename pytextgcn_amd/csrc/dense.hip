@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
                                                    int k, int n, const Drop drop, float *__restrict__ colpart,
                                                    const Place place) {
     extern __shared__ float lds[];  // [kpad][npad] (+ [4][npad] with COLSUM)
+    // the fully unrolled kernels (NQ > 0) only ever run whole products: their placement folds to constants, which
+    // keeps their register budget where it was (they sit at the limit: an accumulator set + the asm load ring)
+    const int p_col0 = NQ > 0 ? 0 : place.col0, p_k0 = NQ > 0 ? 0 : place.k0;
+    const bool p_accum = NQ > 0 ? false : place.accum != 0;
     float csum[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) csum[t] = 0.f;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        if (place.accum) {                     // a later k chunk: continue the sums the earlier launches left in C
+        if (p_accum) {                         // a later k chunk: continue the sums the earlier launches left in C
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = 32 * t + r;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
                 if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
-                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(place.k0 + 8 * q + 4 * half + s4), drop);
+                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
-                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(place.k0 + 8 * q + 4 * half + s4), drop);
+                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
         for (int t = 0; t < NT; ++t) {
             const int col = 32 * t + r;
             if (col < n) {
-                const uint32_t cterm = drop_col_term(place.col0 + col);
+                const uint32_t cterm = drop_col_term(p_col0 + col);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;

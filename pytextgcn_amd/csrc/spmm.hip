@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256) void k_spmm_sub(
 //   * the ds_bpermute source lane is a constant of the unrolled loop (folded into the instruction's offset);
 //   * the four FMAs of an entry are two packed ones (v_pk_fma_f32).
 typedef float pk_f2 __attribute__((ext_vector_type(2)));
-constexpr unsigned kOobOffset = 0xFFFFFF00u;   // beyond any buffer this kernel is launched on (< 0xFFFF0000 bytes)
+// beyond any buffer this kernel is launched on (<= 0xFFFF0000 bytes) AND still beyond it after the largest lane
+// offset is added (31 * 16 = 496 at G = 32): 32-bit offset arithmetic must not wrap back into the buffer
+constexpr unsigned kOobOffset = 0xFFFFF000u;
+static_assert(kOobOffset > 0xFFFF0000u && kOobOffset + 63u * 16u > kOobOffset, "padding offset must stay out of bounds");
 
 template <int G, int U>
 __global__ __launch_bounds__(256) void k_spmm_subb(

@@ -45,8 +45,9 @@ class Adam(Optimizer):
         dW1 = M^T dH1, and `tgcn_spmm_adam` spends each finished row on this optimizer's update of that row
         instead of storing it -- the N x h gradient and the optimizer's own pass over W1 disappear.  The
         parameter then never receives a `.grad`; `step()` skips it and updates the others as usual.  Same bits
-        as backward + step.  Only for loops that call step() after every backward (flat_amazon.py:104-106):
-        gradient accumulation or retain_graph would apply the update once per backward."""
+        as backward + step.  Only for loops that call step() after every backward (flat_amazon.py:104-106): a
+        second backward through the layer before step() (gradient accumulation, retain_graph, two uses of the layer
+        in one loss) would apply the update twice, so it raises instead."""
         if not any(param is p for g in self.param_groups for p in g["params"]):
             raise ValueError("fuse_into_backward: the tensor is not one of this optimizer's parameters")
         key = id(param)
@@ -75,6 +76,12 @@ class Adam(Optimizer):
             return False                      # (widths <= 128 run the sub-group SpMM kernels, which sum in another order)
         lib = _lib.load()
         st, cap = self._state_of(p, group)
+        if st.get("fused_pending", False):
+            raise RuntimeError(
+                "pytextgcn_amd.optim.Adam: a parameter registered with fuse_into_backward() received a second backward "
+                "before step() (gradient accumulation / retain_graph / the layer used twice in one loss): its update "
+                "would be applied twice.  Call step() after every backward, or do not fuse this parameter.")
+        st["fused_pending"] = True
         b1, b2 = group["betas"]
         vmax = st.get("max_exp_avg_sq")
         if cap:
@@ -103,6 +110,9 @@ class Adam(Optimizer):
             b1, b2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
+                    st_ = self.state.get(p)
+                    if st_:
+                        st_["fused_pending"] = False       # its update of this step happened in the backward pass
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("pytextgcn_amd.optim.Adam handles contiguous float32 GPU "

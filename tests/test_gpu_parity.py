@@ -629,6 +629,7 @@ def test_config_c4_w1_update_in_the_backward_spmm_is_bitwise_at_full_size(cuda):
         oa.step()
         wa.grad = None
         assert ob._fused_update(wb, plan, dh)
+        ob.step()                                               # nothing left to do for wb; re-arms the fused update
         assert torch.equal(wa, wb), step
     for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
         assert torch.equal(oa.state[wa][k], ob.state[wb][k]), k
@@ -1744,6 +1745,54 @@ def test_non_finite_operand_rows_with_and_without_the_hot_block(cuda, monkeypatc
     assert set(rows.tolist()) == (set(hubs_without_edge) if F % 4 == 0 else set())
     same = ~differs & fin
     assert (got_h[same] - ref[same]).abs().max().item() < TOL * ref[fin].abs().max().item()
+
+
+@pytest.mark.parametrize("F", [100, 128, 64, 36])
+def test_non_finite_values_in_operand_row_zero_do_not_leak_through_padding(cuda, monkeypatch, F):
+    """The buffer-addressed narrow kernel pads a partly filled group of gathered entries with an out-of-range byte
+    offset (the hardware returns zeros).  The offset must stay out of range after every lane's own 16-byte offset
+    is added -- at 64 < F <= 128 a lane adds up to 496 bytes; an offset that wraps would read X[0, :] and turn
+    0 * inf into nan in rows that have no edge to node 0."""
+    n = 3000
+    gen = torch.Generator().manual_seed(5)
+    g = synth.random_graph(n, 20000, seed=6)
+    ei, w = g.edge_index, g.edge_attr
+    keep = (ei[0] != 0)                                         # nobody gathers node 0 except its own loop
+    ei, w = ei[:, keep], w[keep]
+    x = torch.randn(n, F, generator=gen)
+    x[0, :min(F, 60)] = float("inf")
+    ref = oracle_spmm(ei, w, n, x)
+    monkeypatch.setenv("TGCN_HOT_ROWS", "0")
+    plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
+    got = plan.spmm(x.to(cuda)).cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))
+    assert int((~torch.isfinite(ref)).any(1).sum()) == 1        # only row 0 itself (its self loop)
+    fin = torch.isfinite(ref)
+    assert (got[fin] - ref[fin]).abs().max().item() < TOL * ref[fin].abs().max().item()
+
+
+def test_fused_w1_update_refuses_a_second_backward_before_step(cuda):
+    """optim.Adam.fuse_into_backward applies W1's update inside the backward pass; a second backward before step()
+    (gradient accumulation, retain_graph) would apply it twice -- it must raise, and step() re-arms it."""
+    N, C = 3000, 5
+    g = synth.word_doc_graph(N, 40000, seed=3, device=cuda, n_classes=C)
+    torch.manual_seed(0)
+    model = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0).to(cuda).float()
+    opt = pkg.optim.Adam(model.parameters(), lr=0.01, amsgrad=True)
+    opt.fuse_into_backward(model.layers[0].weight)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def loss():
+        return crit(model(g)[g.train_mask], g.y[g.train_mask])
+    loss().backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss().backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    w_before = model.layers[0].weight.detach().clone()
+    loss().backward()                                           # armed again
+    opt.step()
+    assert not torch.equal(model.layers[0].weight.detach(), w_before)
 
 
 def test_dense_hot_block_is_chosen_for_the_benchmark_shapes_only_when_it_pays(cuda):

@@ -265,3 +265,24 @@ def test_power_law_graph_carries_labels_and_masks():
     assert g.n_vocab == 0 and g.y.shape == (2000,) and int(g.y.max()) < 5
     assert int(g.train_mask.sum() + g.val_mask.sum() + g.test_mask.sum()) == 2000
     assert g.x.is_sparse and g.x.shape == (2000, 2000)
+
+
+def test_build_refuses_spills_in_the_asm_ring_kernels():
+    """pytextgcn_amd/build.py parses hipcc's kernel-resource-usage remarks for dense.hip: a kernel that feeds its
+    operand through an inline-asm load ring (hand-counted s_waitcnt) must not use scratch or spill VGPRs."""
+    from pytextgcn_amd import build
+
+    def remark(name, scratch, vspill):
+        return (f"dense.hip:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]\n"
+                f"remark:     VGPRs: 200 [-R]\nremark:     ScratchSize [bytes/lane]: {scratch} [-R]\n"
+                f"remark:     SGPRs Spill: 3 [-R]\nremark:     VGPRs Spill: {vspill} [-R]\n")
+    ring = "_ZN4tgcn12_GLOBAL__N_111k_gemm_tallILi7ELb1ELb1ELi8ELb1ELb1EEEvPKf"
+    loop = "_ZN4tgcn12_GLOBAL__N_111k_gemm_tallILi8ELb1ELb0ELi0ELb1ELb1EEEvPKf"          # NQ = 0: ordinary loads
+    split = "_ZN4tgcn12_GLOBAL__N_117k_gemm_tall_splitILi2ELb0ELi13ELb1ELb0EEEvPKf"
+    build.check_asm_ring_kernels(remark(ring, 0, 0) + remark(loop, 64, 9) + remark(split, 0, 0))
+    with pytest.raises(RuntimeError, match="must not spill"):
+        build.check_asm_ring_kernels(remark(ring, 152, 37) + remark(split, 0, 0))
+    with pytest.raises(RuntimeError, match="must not spill"):
+        build.check_asm_ring_kernels(remark(ring, 0, 0) + remark(split, 0, 2))
+    with pytest.raises(RuntimeError, match="no kernel-resource-usage remarks"):
+        build.check_asm_ring_kernels(remark(loop, 0, 0))

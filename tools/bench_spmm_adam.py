@@ -47,6 +47,7 @@ def separate():
 
 def fused():
     opt._fused_update(p, plan, gout)
+    opt.state[p]["fused_pending"] = False          # a timing loop: no step() between the calls
 
 
 print(json.dumps({"knobs": {k: v for k, v in os.environ.items() if k.startswith("TGCN_")},
