@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 1
+#define TGCN_ABI_VERSION 2
 
 enum {
     TGCN_OK = 0,
@@ -123,11 +123,7 @@ enum {
     TGCN_Q_HAS_TRANSPOSE = 13,/* 0 for a tgcn_plan_create_coo(with_transpose = 0) plan                */
     TGCN_Q_N_ROWS_T = 14,    /* rows of the transposed block (= columns of the forward block)      */
     TGCN_Q_HOT_ROWS = 15,    /* rows computed by the dense hot block (0 or up to 32), forward block  */
-    TGCN_Q_HOT_ROWS_T = 16,
-    TGCN_Q_SWEEP_ROWS = 17,  /* rows computed by the column-sweep block (0 or 512..4096, padded), forward */
-    TGCN_Q_SWEEP_ROWS_T = 18,
-    TGCN_Q_SWEEP_NNZ = 19,   /* their stored entries, forward block                                  */
-    TGCN_Q_SWEEP_NNZ_T = 20
+    TGCN_Q_HOT_ROWS_T = 16
 };
 int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out);
 

@@ -12,13 +12,13 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
 
 (Q_N_NODES, Q_N_ROWS, Q_NNZ, Q_NNZ_T, Q_SYMMETRIC, Q_ITEMS, Q_ITEMS_T, Q_LONG_ROWS, Q_LONG_ROWS_T,
  Q_SEGMENTS, Q_SEGMENTS_T, Q_DEVICE_BYTES, Q_ROW_BEGIN, Q_HAS_TRANSPOSE, Q_N_ROWS_T, Q_HOT_ROWS,
- Q_HOT_ROWS_T, Q_SWEEP_ROWS, Q_SWEEP_ROWS_T, Q_SWEEP_NNZ, Q_SWEEP_NNZ_T) = range(21)
+ Q_HOT_ROWS_T) = range(17)
 
 # name -> (restype, argtypes); tests/test_abi.py checks this table against include/tgcn.h
 SIGNATURES = {

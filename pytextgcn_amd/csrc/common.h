@@ -70,20 +70,6 @@ struct CsrBlock {
     int32_t hot_cpw = 0;        // columns per wave of k_spmm_hot (even)
     int32_t hot_slot_base = 0;
     float *hot_vals = nullptr;  // [hot_parts * 8 * hot_cpw][kHotRows], zero padded
-    // Column-sweep block (plan.hip: build_items; spmm.hip: k_spmm_sweep).  When n_sweep > 0 the lists above
-    // also leave out the swept rows: the longest rows below the hot ones, as up to 4096 LOCAL rows (a heavy
-    // row is cut into interleaved pieces) packed into 512 wave SLOTS of `sweep_rw` local rows and equal
-    // entry counts.  Their entries are re-sorted by (column block % 8, slot, column block, local row, column)
-    // so that slot s of label x streams ONE contiguous run sweep_cv[sweep_ptr[x * 512 + s] ..
-    // sweep_ptr[x * 512 + s + 1]); entry = {col | row_in_slot << 28, val}.  Partial rows: carry row
-    // sweep_slot_base + sweep_out[local row] + x.
-    int32_t n_sweep = 0;        // padded row count = 512 * sweep_rw (0 = no sweep block)
-    int32_t sweep_rw = 0;       // rows per wave slot (1..8)
-    int32_t sweep_slot_base = 0;
-    int64_t sweep_nnz = 0;
-    int2 *sweep_cv = nullptr;   // [sweep_nnz]
-    int32_t *sweep_ptr = nullptr;  // [8 * 512 + 1]
-    int32_t *sweep_out = nullptr;  // [n_sweep] local row -> its carry row for label 0, relative to sweep_slot_base (-1: unused)
     // The rows of every row block in order of falling degree (plan.hip: build_items), as {first entry, end, row, 0}:
     // the sub-group kernels hand the rows of a block to their 4 (2) sub-groups in THIS order, so that the rows a
     // wave sums side by side have about the same length (a wave runs as many gather rounds as its longest row
@@ -97,10 +83,6 @@ struct CsrBlock {
 };
 
 constexpr int kHotRows = 32;    // one MFMA M-tile
-constexpr int kSweepSlots = 512;   // wave slots of the column sweep: 32 workgroups x 16 waves per label
-constexpr int kSweepLabels = 8;    // one label per XCD (workgroup w is placed on XCD w % 8: speed only)
-constexpr int kSweepWaves = 16;    // waves per workgroup of k_spmm_sweep
-constexpr int kSweepRowShift = 28; // entry.x = col | row_in_slot << 28
 
 void free_block(CsrBlock &b);
 

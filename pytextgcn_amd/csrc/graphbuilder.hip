@@ -283,11 +283,7 @@ int build(tgcn_wwedges &we, const int32_t *X, int64_t D, int64_t L, int64_t V, i
             X, D, L, w, static_cast<int32_t *>(last.p), static_cast<unsigned long long *>(nwin.p));
         TGCN_HIP_CHECK(hipGetLastError());
         const int64_t n = D * L;
-        static const bool privatise = [] {
-            const char *e = std::getenv("TGCN_WW_HOT_PAIRS");
-            return e ? std::atoi(e) != 0 : true;
-        }();
-        if (privatise && V > kHotWords && n >= (int64_t(1) << 16)) {
+        if (V > kHotWords && n >= (int64_t(1) << 16)) {
             // token histogram (vocabulary ids in chunks that fit the LDS), top-H words on the host
             Tmp hist, hot_of_d, hot_word_d;
             TGCN_CHECK(hist.alloc(sizeof(uint32_t) * V));

@@ -340,61 +340,14 @@ __global__ void k_hot_fill(const int32_t *__restrict__ hot_rows, const int32_t *
     }
 }
 
-// Column-sweep block: sort keys of the entries of the swept rows.  Row m of the list (blockIdx.y) is CSR
-// row srow[m], cut into spieces[m] interleaved PIECES (entry j of the row belongs to piece j mod k: every piece
-// spans all columns); piece q is local row piece_li[spbase[m] + q] = slot * rw + row_in_slot.  Entry j goes
-// to position soff[m] + (j - rowptr[row]).  Key = (label * 512 + slot) << 32 | (block >> 3) << 14 | row_in_slot << 11 | column % 2048
-// with block = column / 2048 and label = block % 8: after a stable sort every (label, slot) owns one
-// contiguous run ordered by column block, then row, then column (ties: storage order).
-constexpr int kSweepBlockBits = 11;    // 2048 operand rows per column block (1.6 MB at F = 200)
-
-__global__ void k_sweep_keys(const int32_t *__restrict__ srow, const int32_t *__restrict__ spieces,
-                             const int32_t *__restrict__ spbase, const int32_t *__restrict__ piece_li,
-                             const int64_t *__restrict__ soff, int rw, const int32_t *__restrict__ rowptr,
-                             const int2 *__restrict__ cv, uint64_t *__restrict__ keys, float *__restrict__ vals) {
-    const int m = blockIdx.y;
-    const int32_t r = srow[m], k = spieces[m];
-    const int32_t *li_of = piece_li + spbase[m];
-    const int32_t b = rowptr[r], e = rowptr[r + 1];
-    const int64_t o = soff[m];
-    for (int32_t j = b + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
-        const int2 p = cv[j];
-        const int32_t li = li_of[(j - b) % k];             // entry j of the row belongs to piece j mod k
-        const uint32_t slot = static_cast<uint32_t>(li / rw), ris = static_cast<uint32_t>(li % rw);
-        const uint32_t c = static_cast<uint32_t>(p.x), blk = c >> kSweepBlockBits;
-        const uint64_t hi = (blk & 7u) * kSweepSlots + slot;
-        const uint32_t lo = ((blk >> 3) << 14) | (ris << kSweepBlockBits) | (c & ((1u << kSweepBlockBits) - 1u));
-        keys[o + (j - b)] = (hi << 32) | lo;
-        vals[o + (j - b)] = __int_as_float(p.y);
-    }
-}
-
-__global__ void k_sweep_unpack(const uint64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n,
-                               int2 *__restrict__ scv) {
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint64_t k = keys[j];
-        const uint32_t hi = static_cast<uint32_t>(k >> 32), lo = static_cast<uint32_t>(k);
-        const uint32_t label = hi / kSweepSlots;
-        const uint32_t blk = ((lo >> 14) << 3) | label;
-        const uint32_t col = (blk << kSweepBlockBits) | (lo & ((1u << kSweepBlockBits) - 1u));
-        const uint32_t ris = (lo >> kSweepBlockBits) & 7u;
-        scv[j] = make_int2(static_cast<int>(col | (ris << kSweepRowShift)), __float_as_int(vals[j]));
-    }
-}
-
-// Tuning knobs (tools/sweep_spmm.py); the defaults are the measured best on config c4.
+// Tuning knobs of the work partition (environment, read at plan creation); the defaults are the measured best on
+// config c4.  Launch order is fixed: long-row segments in column-block order with the row blocks spread evenly
+// between them (row order, segments-first, blocks-first and XCD-affine queues were measured and dropped).
 struct Knobs {
-    int col_block;  // columns per block for long-row cuts; 0 = no column cuts
-    int min_piece;  // merge adjacent column blocks of a row until a piece has this many entries
-    int order;      // 0 = row order, 1 = segments first, 2 = row blocks first, 3 = interleaved,
-                    // 4 = interleaved in XCD-affine queues (column block j -> XCD j % 8)
-    int hot_rows;   // 0 = never build the dense hot block
-    double hot_ratio;  // build it when the 32 longest rows hold >= hot_ratio * n_cols entries
-    int sweep_rows;      // most rows the column-sweep block may take (0 = never build it; <= 4096)
-    int sweep_min_rows;  // ... and fewest: below this the block is not worth a launch
-    double sweep_share;  // build it when those rows hold >= sweep_share * nnz entries
-    int sweep_min_cols;  // ... and the operand has at least this many rows (smaller ones sit in L2 anyway)
+    int col_block;  // TGCN_COL_BLOCK: columns per block for long-row cuts; 0 = no column cuts
+    int min_piece;  // TGCN_MIN_PIECE: merge adjacent column blocks of a row until a piece has this many entries
+    int hot_rows;   // TGCN_HOT_ROWS: 0 = never build the dense hot block (pure gather semantics for non-finite operands)
+    double hot_ratio;  // TGCN_HOT_RATIO: build it when the 32 longest rows hold >= hot_ratio * n_cols entries
 };
 
 Knobs knobs_from_env() {
@@ -405,17 +358,9 @@ Knobs knobs_from_env() {
     Knobs k;
     k.col_block = geti("TGCN_COL_BLOCK", 8192);
     k.min_piece = std::max(1, geti("TGCN_MIN_PIECE", 32));
-    k.order = geti("TGCN_ITEM_ORDER", 3);
     k.hot_rows = geti("TGCN_HOT_ROWS", 1);
     const char *hr = std::getenv("TGCN_HOT_RATIO");
     k.hot_ratio = hr ? std::atof(hr) : 2.0;
-    // opt-in (TGCN_SWEEP=1): on config c4 the block moves 10 GB of fabric traffic out of the gather kernel but
-    // costs as much time as it saves (persistent waves drift apart further than the 4 MB an L2 holds)
-    k.sweep_rows = geti("TGCN_SWEEP", 0) ? std::min(geti("TGCN_SWEEP_ROWS", 4096), kSweepSlots * 8) : 0;
-    k.sweep_min_rows = std::max(1, geti("TGCN_SWEEP_MIN_ROWS", 256));
-    const char *ss = std::getenv("TGCN_SWEEP_SHARE");
-    k.sweep_share = ss ? std::atof(ss) : 0.05;
-    k.sweep_min_cols = geti("TGCN_SWEEP_MIN_COLS", 32 << kSweepBlockBits);
     return k;
 }
 
@@ -438,9 +383,6 @@ void free_block(CsrBlock &b) {
     if (b.items_all) (void)hipFree(b.items_all);
     if (b.fix_all) (void)hipFree(b.fix_all);
     if (b.hot_vals) (void)hipFree(b.hot_vals);
-    if (b.sweep_cv) (void)hipFree(b.sweep_cv);
-    if (b.sweep_ptr) (void)hipFree(b.sweep_ptr);
-    if (b.sweep_out) (void)hipFree(b.sweep_out);
     b = CsrBlock{};
 }
 
@@ -489,10 +431,6 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         if (r0 < n_rows) blocks.push_back({r0, n_rows, rp[r0], rp[n_rows]});
     }
     // rows of each block by falling degree (stable: equal degrees keep row order), for the sub-group kernels
-    static const bool sort_rows = [] {
-        const char *e = std::getenv("TGCN_ROW_SORT");
-        return e ? std::atoi(e) != 0 : true;
-    }();
     if (b.row_info) {
         (void)hipFree(b.row_info);
         b.row_info = nullptr;
@@ -507,7 +445,7 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             for (size_t k = b0; k < b1; ++k) {
                 const WorkItem &it = blocks[k];
                 for (int32_t r = it.row_begin; r < it.row_end; ++r) perm[r] = r;
-                if (sort_rows && it.row_end - it.row_begin > 1)
+                if (it.row_end - it.row_begin > 1)
                     std::stable_sort(perm.begin() + it.row_begin, perm.begin() + it.row_end,
                                      [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
                 for (int32_t i = it.row_begin; i < it.row_end; ++i)
@@ -619,181 +557,6 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         b.hot_vals = static_cast<float *>(d_vals.release());
     }
 
-    // The column-sweep block (spmm.hip: k_spmm_sweep).  Below the hot rows sit a few thousand word rows of
-    // 10^3..10^5 entries each.  Gathered row by row they pull every document row across the fabric once per
-    // entry (each is used ~5 times, by rows that run on different XCDs at different times: L2 cannot help).
-    // These rows are taken out of the gather partition too: 8 x 32 persistent workgroups keep their partial
-    // sums in LDS and walk the COLUMNS instead -- label x (one per XCD) takes column blocks b = x (mod 8) in
-    // ascending order, so the 2048 operand rows of a block cross the fabric once, into ONE L2, and serve every
-    // swept row from there.
-    std::vector<int32_t> sweep_of_long(static_cast<size_t>(n_long), -1);   // long-row index -> first carry row
-    std::vector<int32_t> sweep_pieces(static_cast<size_t>(n_long), 0);    // ... and pieces of that row
-    int32_t n_sweep = 0, sweep_rw = 0, sweep_carry_rows = 0;
-    if (kn.sweep_rows > 0 && n_long > 0 && b.n_cols >= kn.sweep_min_cols &&
-        b.n_cols < (int64_t(1) << kSweepRowShift)) {
-        std::vector<int32_t> cand;
-        cand.reserve(n_long);
-        for (int32_t i = 0; i < n_long; ++i)
-            if (hot_of_long[i] < 0) cand.push_back(i);
-        auto deg = [&](int32_t i) { return rp[long_rows[i] + 1] - rp[long_rows[i]]; };
-        std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) {
-            return deg(x) != deg(y) ? deg(x) > deg(y) : x < y;
-        });
-        // A wave slot owns up to 8 local rows and all slots must carry the same number of entries (the
-        // kernel runs as long as its fullest slot), so a row heavier than twice the mean local row is cut
-        // into k interleaved pieces that become local rows of their own (their partial sums are added by
-        // k_spmm_fix like every other partial).  Take as many of the longest rows as then fit 4096 local rows.
-        const int32_t capacity = std::min(kn.sweep_rows, kSweepSlots * 8);
-        size_t take = std::min<size_t>(cand.size(), static_cast<size_t>(capacity));
-        int64_t total = 0, cap = 0, n_local = 0;
-        while (take > 0) {
-            total = 0;
-            for (size_t q = 0; q < take; ++q) total += deg(cand[q]);
-            cap = std::max<int64_t>(64, (2 * total + capacity - 1) / capacity);
-            n_local = 0;
-            for (size_t q = 0; q < take; ++q) n_local += (deg(cand[q]) + cap - 1) / cap;
-            if (n_local <= capacity) break;
-            take = take * 7 / 8;
-        }
-        size_t free_b = 0, total_b = 0;
-        const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-                          static_cast<size_t>(total) * 32 + (size_t(1) << 30) < free_b;
-        (void)hipGetLastError();
-        if (take > 0 && static_cast<int64_t>(take) >= kn.sweep_min_rows && fits &&
-            static_cast<double>(total) >= kn.sweep_share * static_cast<double>(b.nnz)) {
-            sweep_rw = static_cast<int32_t>((n_local + kSweepSlots - 1) / kSweepSlots);
-            n_sweep = sweep_rw * kSweepSlots;
-            // local rows (row pieces), heaviest first, each to the slot that is lightest so far and has room
-            struct Piece {
-                int32_t m, q, size;
-            };
-            std::vector<Piece> pieces;
-            pieces.reserve(static_cast<size_t>(n_local));
-            std::vector<int32_t> srow(take), spieces(take), spbase(take);
-            std::vector<int64_t> soff(take);
-            int64_t off = 0;
-            int32_t max_deg = 0, pb = 0;
-            for (size_t m = 0; m < take; ++m) {
-                const int32_t d = deg(cand[m]), k = static_cast<int32_t>((d + cap - 1) / cap);
-                srow[m] = long_rows[cand[m]];
-                spieces[m] = k;
-                spbase[m] = pb;
-                soff[m] = off;
-                for (int32_t q = 0; q < k; ++q) pieces.push_back({static_cast<int32_t>(m), q, (d - q + k - 1) / k});
-                sweep_of_long[cand[m]] = pb * kSweepLabels;          // carry rows [8 pb, 8 (pb + k)) of the block
-                sweep_pieces[cand[m]] = k;
-                pb += k;
-                off += d;
-                max_deg = std::max(max_deg, d);
-            }
-            sweep_carry_rows = pb * kSweepLabels;
-            std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.size > y.size; });
-            // Slots must carry equal work not only in total but along the way: every wave of a label walks
-            // the columns in the same order, and waves whose rows have their entries in different column
-            // REGIONS (a word row with mostly word neighbours against one with mostly documents) would be
-            // hundreds of column blocks apart most of the time.  The columns are therefore cut into kReg regions
-            // of equal swept mass (from the column-block cut positions of the long rows) and a piece goes to
-            // the slot whose fullest region stays lowest.
-            constexpr int kReg = 16;
-            std::vector<int> region_of(static_cast<size_t>(std::max(n_cb, 1)), 0);
-            const bool by_region = n_cb > 1;
-            if (by_region) {
-                std::vector<int64_t> mass(static_cast<size_t>(n_cb), 0);
-                for (size_t m = 0; m < take; ++m) {
-                    const int32_t *c = cuts.data() + static_cast<size_t>(cand[m]) * (n_cb + 1);
-                    for (int32_t j = 0; j < n_cb; ++j) mass[j] += c[j + 1] - c[j];
-                }
-                int64_t run = 0;
-                for (int32_t j = 0; j < n_cb; ++j) {
-                    region_of[j] = static_cast<int>(std::min<int64_t>(kReg - 1, run * kReg / std::max<int64_t>(total, 1)));
-                    run += mass[j];
-                }
-            }
-            std::vector<double> rvec(take * kReg, 0.0);               // entries of row m in region r
-            std::vector<double> target(kReg, 0.0);
-            for (size_t m = 0; m < take; ++m) {
-                if (by_region) {
-                    const int32_t *c = cuts.data() + static_cast<size_t>(cand[m]) * (n_cb + 1);
-                    for (int32_t j = 0; j < n_cb; ++j) rvec[m * kReg + region_of[j]] += c[j + 1] - c[j];
-                } else {
-                    rvec[m * kReg] = deg(cand[m]);
-                }
-                for (int r = 0; r < kReg; ++r) target[r] += rvec[m * kReg + r] / kSweepSlots;
-            }
-            for (int r = 0; r < kReg; ++r) target[r] = std::max(target[r], 1.0);
-            std::vector<double> load(static_cast<size_t>(kSweepSlots) * kReg, 0.0);
-            std::vector<int32_t> count(kSweepSlots, 0), piece_li(static_cast<size_t>(n_local), 0);
-            std::vector<int32_t> out_row(static_cast<size_t>(n_sweep), -1);   // local row -> carry row of its label 0
-            for (const Piece &pc : pieces) {
-                const double inv_k = 1.0 / spieces[pc.m];
-                int best = -1;
-                double best_cost = 0.0;
-                for (int sl = 0; sl < kSweepSlots; ++sl) {
-                    if (count[sl] >= sweep_rw) continue;
-                    double cost = 0.0;
-                    for (int r = 0; r < kReg; ++r)
-                        cost = std::max(cost, (load[sl * kReg + r] + rvec[pc.m * kReg + r] * inv_k) / target[r]);
-                    if (best < 0 || cost < best_cost) {
-                        best = sl;
-                        best_cost = cost;
-                    }
-                }
-                const int32_t li = best * sweep_rw + count[best];
-                ++count[best];
-                for (int r = 0; r < kReg; ++r) load[best * kReg + r] += rvec[pc.m * kReg + r] * inv_k;
-                piece_li[spbase[pc.m] + pc.q] = li;
-                out_row[li] = (spbase[pc.m] + pc.q) * kSweepLabels;
-            }
-            DevBuf d_row, d_pieces, d_pbase, d_pli, d_off, keys_a, keys_b, vals_a, vals_b, d_scv, d_ptr, d_out;
-            TGCN_CHECK(d_row.alloc(sizeof(int32_t) * take));
-            TGCN_CHECK(d_pieces.alloc(sizeof(int32_t) * take));
-            TGCN_CHECK(d_pbase.alloc(sizeof(int32_t) * take));
-            TGCN_CHECK(d_pli.alloc(sizeof(int32_t) * piece_li.size()));
-            TGCN_CHECK(d_off.alloc(sizeof(int64_t) * take));
-            TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
-            TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
-            TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
-            TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
-            TGCN_CHECK(d_scv.alloc(sizeof(int2) * total));
-            TGCN_CHECK(d_ptr.alloc(sizeof(int32_t) * (kSweepLabels * kSweepSlots + 1)));
-            TGCN_CHECK(d_out.alloc(sizeof(int32_t) * out_row.size()));
-            auto h2d = [&](DevBuf &d, const void *src, size_t bytes) {
-                return hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, stream);
-            };
-            TGCN_HIP_CHECK(h2d(d_row, srow.data(), sizeof(int32_t) * take));
-            TGCN_HIP_CHECK(h2d(d_pieces, spieces.data(), sizeof(int32_t) * take));
-            TGCN_HIP_CHECK(h2d(d_pbase, spbase.data(), sizeof(int32_t) * take));
-            TGCN_HIP_CHECK(h2d(d_pli, piece_li.data(), sizeof(int32_t) * piece_li.size()));
-            TGCN_HIP_CHECK(h2d(d_off, soff.data(), sizeof(int64_t) * take));
-            TGCN_HIP_CHECK(h2d(d_out, out_row.data(), sizeof(int32_t) * out_row.size()));
-            dim3 grid(static_cast<unsigned>(std::min<int64_t>((max_deg + kThreads - 1) / kThreads, 256)),
-                      static_cast<unsigned>(take));
-            k_sweep_keys<<<grid, kThreads, 0, stream>>>(d_row.as<int32_t>(), d_pieces.as<int32_t>(), d_pbase.as<int32_t>(),
-                                                        d_pli.as<int32_t>(), d_off.as<int64_t>(), sweep_rw, b.rowptr, b.cv,
-                                                        keys_a.as<uint64_t>(), vals_a.as<float>());
-            TGCN_HIP_CHECK(hipGetLastError());
-            TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(),
-                                  vals_b.as<float>(), total, 32 + 12, stream));   // syncs: host vectors done
-            k_sweep_unpack<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
-                keys_b.as<uint64_t>(), vals_b.as<float>(), total, d_scv.as<int2>());
-            TGCN_HIP_CHECK(hipGetLastError());
-            k_rowptr<<<grid_for(kSweepLabels * kSweepSlots + 1), kThreads, 0, stream>>>(
-                keys_b.as<uint64_t>(), total, kSweepLabels * kSweepSlots, d_ptr.as<int32_t>());
-            TGCN_HIP_CHECK(hipGetLastError());
-            TGCN_HIP_CHECK(hipStreamSynchronize(stream));
-            b.n_sweep = n_sweep;
-            b.sweep_rw = sweep_rw;
-            b.sweep_nnz = total;
-            b.bytes += d_scv.bytes + d_ptr.bytes + d_out.bytes;
-            b.sweep_cv = static_cast<int2 *>(d_scv.release());
-            b.sweep_ptr = static_cast<int32_t *>(d_ptr.release());
-            b.sweep_out = static_cast<int32_t *>(d_out.release());
-        } else {
-            std::fill(sweep_of_long.begin(), sweep_of_long.end(), -1);
-        }
-    }
-
-
     // pass 2: segments of the long rows, launch order, fix list.  Built once for the complete operator
     // and, when there is a hot block, once more without the hot rows (the list the float4 kernels use
     // next to k_spmm_hot; the complete list then only serves the scalar fallback kernel).
@@ -806,7 +569,6 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
         std::vector<FixEntry> fix;
         int64_t slots = 0;
         int32_t hot_slot_base = 0;
-        int32_t sweep_slot_base = 0;
     };
     bool overflow = false;
     auto make_lists = [&](bool skip_hot, Lists &out) {
@@ -826,7 +588,7 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             }
         };
         for (int32_t i = 0; i < n_long; ++i) {
-            if (skip_hot && (hot_of_long[i] >= 0 || sweep_of_long[i] >= 0)) continue;
+            if (skip_hot && hot_of_long[i] >= 0) continue;
             const int32_t r = long_rows[i];
             const int64_t slot_begin = slots;
             if (n_cb > 0) {
@@ -856,65 +618,16 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
             for (int32_t k = 0; k < n_hot; ++k)
                 fix.push_back({hot_rows[k], static_cast<int32_t>(slots + int64_t(k) * b.hot_parts), b.hot_parts, 0});
             slots += int64_t(n_hot) * b.hot_parts;
-            // swept row cut into k pieces: one partial per piece and label, carry rows [base + first, + 8 k)
-            out.sweep_slot_base = static_cast<int32_t>(slots);
-            for (int32_t i = 0; i < n_long; ++i)
-                if (sweep_of_long[i] >= 0)
-                    fix.push_back({long_rows[i], static_cast<int32_t>(slots + sweep_of_long[i]),
-                                   sweep_pieces[i] * kSweepLabels, 0});
-            slots += sweep_carry_rows;
         }
         if (slots > INT32_MAX || blocks.size() + segs.size() > size_t(INT32_MAX)) overflow = true;
         out.slots = slots;
-        if (kn.order != 0)
-            std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.key < y.key; });
+        std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.key < y.key; });
 
         // launch order
         std::vector<WorkItem> &items = out.items;
         items.reserve(blocks.size() + segs.size() + 64);
-        if (kn.order == 4) {
-            // XCD-affine queues.  Workgroups are dealt round-robin over the 8 XCDs (workgroup w runs on
-            // XCD w % 8; observed placement, used for speed only) and a workgroup holds 4 items, so the
-            // item at launch position p lands on XCD (p / 4) % 8.  All segments of column block j go to
-            // queue j % 8: a slice of X is then pulled through the fabric by ONE XCD's L2 and re-used
-            // there by every long row, instead of being fetched once per XCD.  Row blocks fill the
-            // queues up to equal length; short queues are padded with empty items to keep alignment.
-            constexpr int kXcd = 8, kGroup = 4;
-            std::vector<std::vector<WorkItem>> q(kXcd);
-            std::vector<std::vector<WorkItem>> qseg(kXcd);
-            for (const Seg &sg : segs) qseg[sg.key % kXcd].push_back(sg.it);
-            const size_t total = segs.size() + blocks.size();
-            const size_t per_q = (total + kXcd - 1) / kXcd;
-            size_t bi = 0;
-            for (int x = 0; x < kXcd; ++x) {
-                const size_t ns = qseg[x].size();
-                const size_t nb = ns >= per_q ? 0 : std::min(per_q - ns, blocks.size() - bi);
-                // spread this queue's row blocks evenly between its segments
-                size_t si = 0, bj = 0;
-                while (si < ns || bj < nb) {
-                    if (bj >= nb || (si < ns && si * nb <= bj * ns))
-                        q[x].push_back(qseg[x][si++]);
-                    else
-                        q[x].push_back(blocks[bi + bj++]);
-                }
-                bi += nb;
-            }
-            for (int x = 0; bi < blocks.size(); x = (x + 1) % kXcd) q[x].push_back(blocks[bi++]);
-            size_t longest = 0;
-            for (int x = 0; x < kXcd; ++x) longest = std::max(longest, q[x].size());
-            const WorkItem empty = {0, 0, 0, 0};
-            for (size_t pos = 0; pos < longest; pos += kGroup)
-                for (int x = 0; x < kXcd; ++x)
-                    for (size_t k = pos; k < pos + kGroup; ++k) {
-                        if (k < q[x].size())
-                            items.push_back(q[x][k]);
-                        else if (pos + kGroup < longest || x < kXcd - 1)
-                            items.push_back(empty);
-                    }
-            while (!items.empty() && items.back().nnz_begin == items.back().nnz_end &&
-                   items.back().row_begin == items.back().row_end)
-                items.pop_back();
-        } else if (kn.order == 3) {
+        {
+            // segments in column-block order, the row blocks spread evenly between them
             size_t si = 0, bi = 0;
             const size_t ns = segs.size(), nb = blocks.size();
             while (si < ns || bi < nb) {
@@ -923,12 +636,6 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
                 else
                     items.push_back(blocks[bi++]);
             }
-        } else if (kn.order == 2) {
-            items = blocks;
-            for (const Seg &sg : segs) items.push_back(sg.it);
-        } else {
-            for (const Seg &sg : segs) items.push_back(sg.it);
-            items.insert(items.end(), blocks.begin(), blocks.end());
         }
     };
 
@@ -954,13 +661,12 @@ int build_items(CsrBlock &b, int T, hipStream_t stream) {
     };
 
     Lists main_lists;
-    make_lists(n_hot > 0 || n_sweep > 0, main_lists);
+    make_lists(n_hot > 0, main_lists);
     if (!overflow) {
         b.hot_slot_base = main_lists.hot_slot_base;
-        b.sweep_slot_base = main_lists.sweep_slot_base;
         TGCN_CHECK(upload(main_lists, b.items, b.n_items, b.fix, b.n_fix, b.n_segments));
     }
-    if ((n_hot > 0 || n_sweep > 0) && !overflow) {
+    if (n_hot > 0 && !overflow) {
         Lists all;
         make_lists(false, all);
         if (!overflow) TGCN_CHECK(upload(all, b.items_all, b.n_items_all, b.fix_all, b.n_fix_all, b.n_segments_all));
@@ -1336,10 +1042,6 @@ int tgcn_plan_query(const tgcn_plan *plan, int what, int64_t *out) {
         case TGCN_Q_N_ROWS_T: *out = t.n_rows; break;
         case TGCN_Q_HOT_ROWS: *out = f.n_hot; break;
         case TGCN_Q_HOT_ROWS_T: *out = t.n_hot; break;
-        case TGCN_Q_SWEEP_ROWS: *out = f.n_sweep; break;
-        case TGCN_Q_SWEEP_ROWS_T: *out = t.n_sweep; break;
-        case TGCN_Q_SWEEP_NNZ: *out = f.sweep_nnz; break;
-        case TGCN_Q_SWEEP_NNZ_T: *out = t.sweep_nnz; break;
         default:
             set_error("tgcn_plan_query: unknown selector %d", what);
             return TGCN_E_INVALID;

@@ -289,98 +289,14 @@ __global__ __launch_bounds__(256) void k_spmm_gather_adam(
                              nullptr, 0, carry, ldc, ad);
 }
 
-// Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row): the wave splits into
-// S = 64 / G sub-groups.  In a row block every sub-group walks its OWN rows (row_begin + sub, + S,
-// ...), so S rows are gathered per wave instruction and no cross-lane reduction is needed; in a
-// long-row segment the sub-groups take entries sub, sub + S, ... and their partial sums are combined
-// with wavefront shuffles (xor G, 2G) before the carry row is written.  A sub-group loads G
-// (col,val) pairs with one coalesced instruction and hands them round with ds_bpermute.
-template <int G, int U>
-__global__ __launch_bounds__(256) void k_spmm_sub(
-    const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
-    const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx,
-    const float *__restrict__ X2, int64_t ldx2, int split, int F, const float *__restrict__ bias,
-    float *__restrict__ Y, int64_t ldy, float *__restrict__ carry, int64_t ldc) {
-    constexpr int S = 64 / G;
-    const int lane = threadIdx.x & 63;
-    const int item_id =
-        __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (item_id >= n_items) return;
-    const int sub = lane / G, sl = lane % G;
-    const int nvec = F / 4;                                    // <= G (checked by the launcher)
-    const bool active = sl < nvec;
-    const int lc = (active ? sl : nvec - 1) * 4;
-    const WorkItem it = items[item_id];
-    const bool segment = it.row_end < 0;
-    float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias != nullptr) bvec = *reinterpret_cast<const float4 *>(bias + lc);
-    const float *xl = X + lc;
-    const float *xl2 = X2 + lc - int64_t(split) * ldx2;
-
-    // sum over entries start, start + stride, ... < end (per sub-group values)
-    auto run = [&](int start, int stride, int end) -> float4 {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t0 = start; t0 < end; t0 += G * stride) {
-            const int my = t0 + sl * stride;
-            int2 e = cv[min(my, end - 1)];                     // unconditional load, clamped index
-            if (my >= end) e.y = 0;                            // padding: weight 0
-            const int nb = min(G, (end - t0 + stride - 1) / stride);
-            for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 x[U];
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int src = (sub * G + min(u0 + u, G - 1)) * 4;
-                    const int c = __builtin_amdgcn_ds_bpermute(src, e.x);
-                    v[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, e.y));
-                    if (u0 + u >= G) v[u] = 0.f;
-                    const float *xsrc = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
-                    x[u] = *reinterpret_cast<const float4 *>(xsrc);
-                    // padding entries (weight 0) re-read the last real column: their operand must not
-                    // reach the sum, or 0 * inf = nan would appear where the reference has inf
-                    if (u0 + u >= nb) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    acc.x = fmaf(v[u], x[u].x, acc.x);
-                    acc.y = fmaf(v[u], x[u].y, acc.y);
-                    acc.z = fmaf(v[u], x[u].z, acc.z);
-                    acc.w = fmaf(v[u], x[u].w, acc.w);
-                }
-            }
-        }
-        return acc;
-    };
-
-    if (segment) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it.nnz_begin + sub < it.nnz_end) acc = run(it.nnz_begin + sub, S, it.nnz_end);
-#pragma unroll
-        for (int off = G; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off, 64);
-            acc.y += __shfl_xor(acc.y, off, 64);
-            acc.z += __shfl_xor(acc.z, off, 64);
-            acc.w += __shfl_xor(acc.w, off, 64);
-        }
-        const int slot = -it.row_end - 1;
-        if (sub == 0 && active) *reinterpret_cast<float4 *>(carry + int64_t(slot) * ldc + lc) = acc;
-    } else {
-        for (int r = it.row_begin + sub; r < it.row_end; r += S) {
-            const int b = rowptr[r], e = rowptr[r + 1];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < e) acc = run(b, 1, e);
-            if (active)
-                *reinterpret_cast<float4 *>(Y + int64_t(r) * ldy + lc) =
-                    make_float4(acc.x + bvec.x, acc.y + bvec.y, acc.z + bvec.z, acc.w + bvec.w);
-        }
-    }
-}
-
-// Narrow rows, buffer-addressed form (the common case: one operand buffer below 4 GB).  Same work split as
-// k_spmm_sub; what changes is the cost of an entry.  The PMC profile of k_spmm_sub on c4, F = 64
-// (profiles/r02a_pmc_c4_f64_before_sweep.md) shows 19.5 vector-ALU instructions per gather instruction and the
-// VALU busy 66 % of the time: 64-bit address arithmetic, the split-operand select and the lane-index arithmetic
-// of ds_bpermute, per entry.  Here
+// Narrow rows (F <= 4 G floats, G = 16 or 32 lanes per gathered row; one operand buffer below 4 GB): the wave
+// splits into S = 64 / G sub-groups.  In a row block every sub-group walks its OWN rows, so S rows are gathered per
+// wave instruction and no cross-lane reduction is needed; in a long-row segment the sub-groups take entries sub,
+// sub + S, ... and their partial sums are combined with wavefront shuffles (xor G, 2G) before the carry row is
+// written.  A sub-group loads G (col,val) pairs with one coalesced instruction and hands them round with
+// ds_bpermute.  The first form of this kernel (round 1, global-pointer gathers) spent 19.5 vector-ALU instructions
+// per gather instruction (profiles/r02a_pmc_c4_f64_before_sweep.md: 64-bit address arithmetic, operand select,
+// lane-index arithmetic); here
 //   * the lane that loads a (col, val) pair turns the column into a 32-bit BYTE OFFSET once (one multiply per
 //     16 entries instead of one 64-bit multiply-add per gather); padding lanes get an offset beyond the buffer;
 //   * a gather is `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`: the hardware adds the base, and an offset
@@ -574,91 +490,6 @@ __global__ __launch_bounds__(64 * kHotWaves) void k_spmm_hot(
     }
 }
 
-// Column sweep (plan.hip: the sweep block).  8 labels x 32 workgroups of 16 waves; wave `slot` of label x owns
-// `rw` of the swept rows and ONE contiguous run of their entries: those whose column block (2048 operand
-// rows) is = x (mod 8), ordered by column block, then row, then column.  Workgroups of one label run on one
-// XCD (workgroups are dealt round-robin over the XCDs; an observed placement that only speed depends on)
-// and walk the column blocks in the same order at the same pace -- every slot carries the same share of the
-// entries -- so a block's operand rows are fetched over the fabric once, into that XCD's L2, and gathered
-// from there by all 512 waves of the label.  The partial sums of a wave's rows live in LDS (rw x F floats
-// per wave, up to 128 KB per workgroup); the row being accumulated sits in registers and is exchanged with
-// its LDS copy when the stream moves to another row (a wave-uniform branch: the row index comes out of
-// v_readlane).  No wave ever touches another wave's rows: no barriers, no atomics, fixed summation order.
-// At the end every wave writes its rows as partial sums of label x; k_spmm_fix adds the 8 labels in order.
-template <int VEC, int U>
-__global__ __launch_bounds__(64 * kSweepWaves) void k_spmm_sweep(
-    const int2 *__restrict__ scv, const int32_t *__restrict__ sptr, int rw, const float *__restrict__ X,
-    int64_t ldx, const float *__restrict__ X2, int64_t ldx2, int split, int F, int tw, float *__restrict__ carry,
-    int64_t ldc, int slot_base, const int32_t *__restrict__ out_row) {
-    using V = Vec<VEC>;
-    using vec_t = typename V::type;
-    extern __shared__ __attribute__((aligned(16))) float sweep_acc[];   // [kSweepWaves * rw][tw]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int label = blockIdx.x & (kSweepLabels - 1);
-    const int slot = (blockIdx.x / kSweepLabels) * kSweepWaves + wave;
-    const int col0 = blockIdx.y * tw;                           // column tile of tw <= 64 VEC floats (tw % VEC == 0)
-    const int nvec = (min(F - col0, tw) + VEC - 1) / VEC;
-    const bool active = lane < nvec;
-    const int lv = (active ? lane : nvec - 1) * VEC;            // idle lanes shadow the last vector, never store
-    const int wl = tw;                                          // LDS row length
-    float *mine = sweep_acc + (wave * rw) * wl + lv;
-    for (int k = 0; k < rw; ++k)
-        if (active) *reinterpret_cast<vec_t *>(mine + k * wl) = V::zero();
-    const float *xl = X + col0 + lv;
-    const float *xl2 = X2 + col0 + lv - int64_t(split) * ldx2;
-    const int b = sptr[label * kSweepSlots + slot], e = sptr[label * kSweepSlots + slot + 1];
-
-    auto load_cv = [&](int idx) -> int2 {
-        const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long *>(scv + idx));
-        return make_int2(static_cast<int>(raw), static_cast<int>(raw >> 32));
-    };
-    int cur = -1;                                               // row (of this wave's rw) held in `acc`
-    vec_t acc = V::zero();
-    int2 nxt = make_int2(0, 0);
-    if (b + lane < e) nxt = load_cv(b + lane);
-    for (int base = b; base < e; base += 64) {
-        const int2 me = nxt;
-        nxt = make_int2(0, 0);                                  // col 0 / row 0 / weight 0 for the padded tail
-        if (base + 64 + lane < e) nxt = load_cv(base + 64 + lane);
-        const int n = min(64, e - base);
-        for (int j0 = 0; j0 < n; j0 += U) {
-            vec_t x[U];
-            float v[U];
-            int ri[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const unsigned cx = static_cast<unsigned>(readlane_i(me.x, j0 + u));
-                v[u] = readlane_f(me.y, j0 + u);
-                ri[u] = static_cast<int>(cx >> kSweepRowShift);
-                const int c = static_cast<int>(cx & ((1u << kSweepRowShift) - 1u));
-                const float *src = c < split ? xl + int64_t(c) * ldx : xl2 + int64_t(c) * ldx2;
-                x[u] = *reinterpret_cast<const vec_t *>(src);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (base + j0 + u < e) {
-                    if (ri[u] != cur) {
-                        if (cur >= 0 && active) *reinterpret_cast<vec_t *>(mine + cur * wl) = acc;
-                        cur = ri[u];
-                        acc = *reinterpret_cast<const vec_t *>(mine + cur * wl);
-                    }
-                    V::fma(acc, v[u], x[u]);
-                }
-            }
-        }
-    }
-    if (cur >= 0 && active) *reinterpret_cast<vec_t *>(mine + cur * wl) = acc;
-    if (active) {
-        for (int k = 0; k < rw; ++k) {
-            const int o = out_row[slot * rw + k];               // -1: this slot holds fewer than rw rows
-            if (o < 0) continue;
-            const int64_t row = int64_t(slot_base) + o + label;
-            *reinterpret_cast<vec_t *>(carry + row * ldc + col0 + lv) = *reinterpret_cast<const vec_t *>(mine + k * wl);
-        }
-    }
-}
-
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
 template <int VEC, bool ADAM = false>
@@ -715,73 +546,12 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
     }
 }
 
-// A/B knob (tools/sweep_spmm.py): TGCN_SPMM_VARIANT = "8:0" selects the kernel without cache hints.
-// Other unroll depths (4, 16) and hint sets were measured within +-2 % and dropped.
-int variant_from_env() {
-    static const int v = [] {
-        const char *s = std::getenv("TGCN_SPMM_VARIANT");
-        int u = 8, pol = 3;  // measured best on c4: 8 rows in flight, streams marked non-temporal
-        if (s) std::sscanf(s, "%d:%d", &u, &pol);
-        return u * 16 + (pol & 7);
-    }();
-    return v;
-}
-
-bool narrow_from_env() {
-    static const bool on = [] {
-        const char *s = std::getenv("TGCN_SPMM_NARROW");
-        return s ? std::atoi(s) != 0 : true;
-    }();
-    return on;
-}
-
-bool narrow_buf_from_env() {
-    static const bool on = [] {
-        const char *s = std::getenv("TGCN_SPMM_NARROW_BUF");
-        return s ? std::atoi(s) != 0 : true;
-    }();
-    return on;
-}
-
 template <int NT>
 void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
                 float *carry, int64_t ldc, hipStream_t stream) {
     dim3 grid(b.hot_parts, (F + 32 * NT - 1) / (32 * NT));
     k_spmm_hot<NT><<<grid, 64 * kHotWaves, 0, stream>>>(b.hot_vals, b.n_cols, b.hot_cpw, X, ldx, X2, ldx2, split, F,
                                                        carry, ldc, b.hot_slot_base, b.hot_parts, b.n_hot);
-}
-
-// Column tiles of the sweep: 64 VEC floats wide at most, equal widths, run one after the other (grid.y).
-// TGCN_SWEEP_VEC = 1 / 2 / 4 floats per lane (A/B knob).  Narrow tiles were tried as a way to keep more operand
-// rows in the 4 MB L2 while the waves of a label drift apart (at 64 floats per tile it holds 16 000 rows): the hit
-// rate did not move (41 % against 43 %) and four passes cost more than they save.
-int sweep_vec_from_env() {
-    static const int v = [] {
-        const char *s = std::getenv("TGCN_SWEEP_VEC");
-        const int x = s ? std::atoi(s) : 4;
-        return (x == 1 || x == 2 || x == 4) ? x : 4;
-    }();
-    return v;
-}
-
-template <int VEC>
-int launch_sweep(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
-                 float *carry, int64_t ldc, hipStream_t stream) {
-    constexpr int U = 8;
-    const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
-    const int tw = (((F + tiles - 1) / tiles) + 3) & ~3;       // equal tiles, multiple of 4 floats (16-byte pieces)
-    const size_t lds = sizeof(float) * static_cast<size_t>(kSweepWaves) * b.sweep_rw * tw;   // <= 128 KB
-    static std::atomic<size_t> granted{48 * 1024};
-    if (lds > granted.load()) {
-        TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmm_sweep<VEC, U>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        granted.store(lds);
-    }
-    dim3 grid(kSweepLabels * (kSweepSlots / kSweepWaves), (F + tw - 1) / tw);
-    k_spmm_sweep<VEC, U><<<grid, 64 * kSweepWaves, lds, stream>>>(b.sweep_cv, b.sweep_ptr, b.sweep_rw, X, ldx, X2, ldx2,
-                                                                 split, F, tw, carry, ldc, b.sweep_slot_base, b.sweep_out);
-    TGCN_HIP_CHECK(hipGetLastError());
-    return TGCN_OK;
 }
 
 // `ad` != nullptr (VEC == 4 only): the finished rows are spent on the optimizer instead of being stored in Y
@@ -799,7 +569,7 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         const FixEntry *fix;
         int32_t n_fix;
     };
-    const bool all = VEC == 1 && (blk.n_hot > 0 || blk.n_sweep > 0);
+    const bool all = VEC == 1 && blk.n_hot > 0;
     const View b = all ? View{blk.items_all, blk.n_items_all, blk.fix_all, blk.n_fix_all}
                        : View{blk.items, blk.n_items, blk.fix, blk.n_fix};
     const int32_t *rowptr = blk.rowptr;
@@ -818,21 +588,11 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         }
         TGCN_HIP_CHECK(hipGetLastError());
     }
-    if (VEC == 4 && blk.n_sweep > 0) {
-        // lanes own 4 floats of a row (measured best on c4: 1.0 ms against 1.7 ms for one float per lane in
-        // four narrow column tiles); narrow widths always take one float per lane (full wavefronts at F <= 64)
-        const int v = F <= 64 ? 1 : (F <= 128 ? std::min(2, sweep_vec_from_env()) : sweep_vec_from_env());
-        switch (v) {
-            case 4: TGCN_CHECK(launch_sweep<4>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
-            case 2: TGCN_CHECK(launch_sweep<2>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
-            default: TGCN_CHECK(launch_sweep<1>(blk, X, ldx, X2, ldx2, split, F, carry, ldc, stream)); break;
-        }
-    }
     if (b.n_items > 0) {
         dim3 grid((b.n_items + kWavesPerBlock - 1) / kWavesPerBlock, tiles);
         // operand as one buffer below 4 GB (and rows addressable with 32-bit byte offsets): buffer-addressed form
         const uint64_t x_extent = (static_cast<uint64_t>(blk.n_cols - 1) * static_cast<uint64_t>(ldx) + F) * 4u;
-        const bool buf_ok = split == INT32_MAX && x_extent <= 0xFFFF0000ull && narrow_buf_from_env();
+        const bool buf_ok = split == INT32_MAX && x_extent <= 0xFFFF0000ull;
         if (ad != nullptr) {
             if constexpr (VEC == 4) {
                 // U = 2 / 4 / 8 gathered rows in flight measured the same (5.62-5.66 ms at c4): the launch is bound by
@@ -840,10 +600,10 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
                 k_spmm_gather_adam<4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split, F,
                                                                 bias, carry, ldc, *ad);
             }
-        } else if (VEC == 4 && F <= 128 && narrow_from_env() && buf_ok) {
-            // U = 4 gathers in flight per sub-group: 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows
-            // hold ~10 entries and every started group of U is gathered in full
-            // (with the rows of a block sorted by degree U = 4 is still the best: 2 / 8 measured 10 % / 8 % slower)
+        } else if (VEC == 4 && F <= 128 && buf_ok) {
+            // narrow feature rows (the layer-2 width C): sub-group kernel.  U = 4 gathers in flight per sub-group:
+            // 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows hold ~10 entries and every started
+            // group of U is gathered in full (with the rows of a block sorted by degree 2 / 8 measured 10 % / 8 % slower)
             if (F <= 64)
                 k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
                                                             static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
@@ -852,27 +612,15 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
                 k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
                                                             static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
                                                             blk.row_info);
-        } else if (VEC == 4 && F <= 128 && narrow_from_env()) {
-            // narrow feature rows (the layer-2 width C): sub-group kernel
-            if (F <= 64)
-                k_spmm_sub<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2,
-                                                           split, F, bias, Y, ldy, carry, ldc);
-            else
-                k_spmm_sub<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2,
-                                                           split, F, bias, Y, ldy, carry, ldc);
         } else {
-#define TGCN_LAUNCH(UU, PP)                                                                      \
-    k_spmm_gather<VEC, UU, PP><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, \
-                                                         split, F, bias, Y, ldy, carry, ldc)
-            if constexpr (VEC == 4) {
-                switch (variant_from_env()) {
-                    case 8 * 16 + 0: TGCN_LAUNCH(8, 0); break;   // plain loads / stores (for A/B runs)
-                    default: TGCN_LAUNCH(8, 3); break;           // streams non-temporal (measured best)
-                }
-            } else {
-                TGCN_LAUNCH(8, 0);
-            }
-#undef TGCN_LAUNCH
+            // full-wave kernel: wide rows, split operands, operands beyond 4 GB, unaligned / odd widths (VEC = 1).
+            // Streams ((col,val) pairs, result rows) are marked non-temporal on the float4 path (measured best on c4)
+            if constexpr (VEC == 4)
+                k_spmm_gather<4, 8, 3><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split, F,
+                                                                 bias, Y, ldy, carry, ldc);
+            else
+                k_spmm_gather<VEC, 8, 0><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split,
+                                                                   F, bias, Y, ldy, carry, ldc);
         }
         TGCN_HIP_CHECK(hipGetLastError());
     }

@@ -355,11 +355,8 @@ static int masked_ce_impl(const char *who, const float *logits, int64_t ld, int6
     } while (0)
     // Logits per lane on the register path: 8 (half the lanes per row, one shuffle level less in each of the three
     // row reductions) measured 0.247 -> 0.149 ms without and 0.308 -> 0.232 ms with the gradient at c4 (2 M x 64);
-    // 16 was slower again (0.17 / 0.28 ms).  TGCN_CE_KPL=4 selects the round-1 layout.
-    static const int kpl = [] {
-        const char *e = std::getenv("TGCN_CE_KPL");
-        return e && std::atoi(e) == 4 ? 4 : 8;
-    }();
+    // 16 was slower again (0.17 / 0.28 ms).  Four per lane remains for C <= 16.
+    constexpr int kpl = 8;
     if (kpl == 8 && C > 16 && C <= 256) {
         // eight logits per lane: half the lanes per row, one reduction level less
         rows_per_block = 2 * 4 * (C <= 32 ? 16 : C <= 64 ? 8 : C <= 128 ? 4 : 2);
@@ -489,12 +486,8 @@ static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp
         TGCN_HIP_CHECK(hipGetLastError());
         if (n == 0) return TGCN_OK;   // n = 0: only advance the device step (tgcn_spmm_adam applies the update)
     }
-    // large tensors (W1: N x h) stream their state past the caches; TGCN_ADAM_NT=0/1 forces either form
-    static const int nt_env = [] {
-        const char *e = std::getenv("TGCN_ADAM_NT");
-        return e ? std::atoi(e) : -1;
-    }();
-    const bool nt = nt_env >= 0 ? nt_env != 0 : n >= (int64_t(1) << 24);
+    // large tensors (W1: N x h) stream their state past the caches (measured: 2.9 -> 2.5 ms on 2 M x 200)
+    const bool nt = n >= (int64_t(1) << 24);
 #define TGCN_ADAM(AMS, NTV)                                                                                  \
     k_adam<AMS, NTV><<<grid, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, AMS ? max_exp_avg_sq : nullptr, n, w1, \
                                           b2f, w2, epsf, wdf, step_size, inv_bc2_sqrt, scalars_dev)

@@ -121,8 +121,7 @@ class GraphPlan:
         return {"n_nodes": self.num_nodes, "n_rows": self.n_rows, "nnz": self.nnz,
                 "symmetric": self.symmetric, "items": self.query(_lib.Q_ITEMS),
                 "long_rows": self.query(_lib.Q_LONG_ROWS), "segments": self.query(_lib.Q_SEGMENTS),
-                "hot_rows": self.query(_lib.Q_HOT_ROWS), "sweep_rows": self.query(_lib.Q_SWEEP_ROWS),
-                "sweep_nnz": self.query(_lib.Q_SWEEP_NNZ), "device_bytes": self.query(_lib.Q_DEVICE_BYTES)}
+                "hot_rows": self.query(_lib.Q_HOT_ROWS), "device_bytes": self.query(_lib.Q_DEVICE_BYTES)}
 
     def algorithmic_bytes(self, F: int, bias: bool = False, transpose: bool = False) -> int:
         """SURVEY.md 8(d) / BASELINE.md gather model, unpadded F, no cache reuse assumed:

@@ -469,18 +469,32 @@ class ShardedGraph:
             self._stage[key] = buf
         return buf
 
+    _NARROW = 128     # widths up to here run the sub-group SpMM kernels, which take ONE operand buffer
+
     def _gather_buffer(self, x_local: Tensor, halo: bool) -> Tensor:
         """The gathered hub block [W * hp, F], one per width (layer-1 / layer-2 widths alternate).  The halo form
         has its own, zero-filled once: it only ever writes the rows B_r references, and the rest must stay finite
-        (the dense hot block of a local operator multiplies EVERY operand row by a possibly zero weight)."""
+        (the dense hot block of a local operator multiplies EVERY operand row by a possibly zero weight).
+        Narrow widths (the class width of layer 2) get rp more rows behind the block: B_r's whole operand [hubs ;
+        own regular rows] in one buffer, which is what the sub-group kernels gather from (the copy of the own rows
+        is rp x F floats; at wide widths B_r reads them in place as a split operand)."""
         F = x_local.size(1)
         key = (F, x_local.dtype, x_local.device, halo)
         xbuf = self._xbuf.get(key)
         if xbuf is None:
             make = torch.zeros if halo else torch.empty
-            xbuf = make(self.world * self.hp, F, dtype=x_local.dtype, device=x_local.device)
+            rows = self.world * self.hp + (self.rp if F <= self._NARROW else 0)
+            xbuf = make(rows, F, dtype=x_local.dtype, device=x_local.device)
             self._xbuf[key] = xbuf
-        return xbuf
+        return xbuf[:self.world * self.hp]
+
+    def _whole_operand(self, xbuf: Tensor, x_local: Tensor) -> Optional[Tensor]:
+        """[gathered hubs ; own regular rows] as one tensor when the width calls for it (see _gather_buffer)."""
+        if self.rp == 0 or x_local.size(1) > self._NARROW:
+            return None
+        whole = self._xbuf[(x_local.size(1), x_local.dtype, x_local.device, self.exchange == "halo")]
+        whole[self.world * self.hp:].copy_(x_local[self.hp:])
+        return whole
 
     def _start_gather(self, d: _Direction, x_local: Tensor):
         """Start bringing the hub rows this rank's B_r reads into the gather buffer.  Returns (buffer, finish):
@@ -582,9 +596,13 @@ class ShardedGraph:
             xr = x_local[hp:]
             for ch in d.chunks[self.rs_chunks]:
                 pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
+        whole = self._whole_operand(xbuf, x_local)             # narrow widths: own rows copied behind the hub block
         gathered()
-        # split operand: hub columns from the gathered block, own regular columns straight from x_local
-        y = d.B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)   # overlaps the reduce-scatter
+        if whole is not None:
+            y = d.B.spmm(whole, bias)                                       # overlaps the reduce-scatter
+        else:
+            # split operand: hub columns from the gathered block, own regular columns straight from x_local
+            y = d.B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)
         for finish in pending:
             finish(y[:hp])
         return y

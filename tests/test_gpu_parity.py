@@ -1371,14 +1371,13 @@ def test_compute_entry_points_are_hipgraph_capturable(cuda):
 
 def test_work_partition_stress_with_tiny_blocks(cuda, monkeypatch):
     """Many small random graphs with the partition knobs turned down (item weight 64, column blocks
-    of 16, pieces >= 4), so that every cut / merge / tail path of plan.hip:build_items runs, in all
-    launch orders, for the full-wave and the sub-group kernels."""
+    of 16, pieces >= 4), so that every cut / merge / tail path of plan.hip:build_items runs, for the
+    full-wave and the sub-group kernels."""
     gen = torch.Generator().manual_seed(123)
     for trial in range(24):
         monkeypatch.setenv("TGCN_ITEM_WEIGHT", "64")
         monkeypatch.setenv("TGCN_COL_BLOCK", str([16, 7, 64, 0][trial % 4]))
         monkeypatch.setenv("TGCN_MIN_PIECE", str([4, 1, 9][trial % 3]))
-        monkeypatch.setenv("TGCN_ITEM_ORDER", str([3, 4, 0, 1, 2][trial % 5]))
         n = int(torch.randint(2, 700, (1,), generator=gen))
         e = int(torch.randint(0, 9000, (1,), generator=gen))
         g = synth.random_graph(n, e, seed=trial, self_loops=trial % 5, duplicates=(trial * 7) % 40)
@@ -1649,62 +1648,6 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
     plan.close(); plain.close()
 
 
-@pytest.mark.parametrize("n,n_hubs,weight,dup", [(20011, 40, 192, False), (9001, 33, 64, True), (30000, 600, 64, False)])
-def test_column_sweep_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_hubs, weight, dup):
-    """k_spmm_sweep (opt-in, TGCN_SWEEP=1): the long rows below the hot ones, accumulated in LDS while 8 x 32
-    workgroups walk the column blocks.  Thresholds are lowered so that graphs of test size get the block (the
-    defaults ask for >= 256 such rows and >= 65 536 operand rows); checked against the oracle and against the
-    same graph's plan without it for every lane width of the sweep (1, 2, 4 floats per lane, several column
-    tiles), heavy rows cut into pieces, the transposed block of an asymmetric operator, split operands and
-    strided results."""
-    gen = torch.Generator().manual_seed(n)
-    if n_hubs > 100:                                  # many mid-length rows: every wave slot gets several rows
-        srcs, dsts = [], []
-        for h in range(n_hubs):
-            others = torch.randint(0, n, (int(300 + 5 * (h % 97)),), generator=gen)
-            others = others[others != h]
-            srcs += [others, torch.full_like(others, h)]
-            dsts += [torch.full_like(others, h), others]
-        ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
-        w = torch.rand(ei.shape[1], generator=gen) + 0.05
-    else:
-        ei, w = _hub_graph(n, n_hubs, gen, dup)
-    monkeypatch.setenv("TGCN_ITEM_WEIGHT", str(weight))
-    monkeypatch.setenv("TGCN_SWEEP", "1")             # the block is opt-in (DESIGN.md 4.7)
-    monkeypatch.setenv("TGCN_SWEEP_MIN_ROWS", "1")
-    monkeypatch.setenv("TGCN_SWEEP_MIN_COLS", "1")
-    monkeypatch.setenv("TGCN_SWEEP_SHARE", "0")
-    plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
-    st = plan.stats()
-    assert st["sweep_rows"] >= 512 and st["sweep_rows"] % 512 == 0 and st["sweep_nnz"] > 0
-    if n_hubs > 100:
-        assert st["sweep_rows"] >= 1024               # 600 rows in pieces -> several local rows per wave slot
-    assert plan.query(_lib.Q_SWEEP_ROWS_T) >= 512 and not plan.symmetric
-    monkeypatch.setenv("TGCN_SWEEP", "0")
-    plain = GraphPlan(ei.to(cuda), w.to(cuda), n)
-    assert plain.stats()["sweep_rows"] == 0
-    monkeypatch.setenv("TGCN_SWEEP", "1")
-    for F in (200, 64, 8, 132, 260, 520, 100, 7):
-        x = torch.randn(n, F, generator=gen)
-        b = torch.randn(F, generator=gen)
-        xd, bd = x.to(cuda), b.to(cuda)
-        for transpose in (False, True):
-            ref = oracle_spmm(ei, w, n, x, None if transpose else b, transpose=transpose)
-            got = plan.spmm(xd, None if transpose else bd, transpose=transpose)
-            assert rel_err(got, ref) < TOL, (F, transpose)
-            assert rel_err(got, plain.spmm(xd, None if transpose else bd, transpose=transpose)) < TOL
-            assert torch.equal(got, plan.spmm(xd, None if transpose else bd, transpose=transpose))  # reproducible
-        if F % 4 == 0:
-            split = n // 3
-            hi = torch.randn(n, F, device=cuda)
-            hi[11:11 + n - split] = xd[split:]
-            got = plan.spmm(xd[:split].contiguous(), bd, x2=hi[11:11 + n - split])
-            assert torch.equal(got, plan.spmm(xd, bd))
-            out = torch.full((n, F + 8), 3.0, device=cuda)
-            plan.spmm(xd, bd, out=out[:, 4:4 + F])
-            assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and (out[:, :4] == 3).all() and (out[:, 4 + F:] == 3).all()
-
-
 @pytest.mark.parametrize("F", [200, 64, 32, 7])          # wide, sub-group (16 / 8 lanes per row) and scalar kernels
 def test_non_finite_operand_rows_with_and_without_the_hot_block(cuda, monkeypatch, F):
     """An `inf` in ONE operand row.  Reference semantics (gather -> scale -> scatter_add, models.py:20): it
@@ -1955,15 +1898,14 @@ def test_graphed_training_with_fused_dropout_draws_a_new_mask_per_replay(cuda):
     assert max(losses) - min(losses) < 0.2 * abs(losses[0])          # same weights, different masks
 
 
-@pytest.mark.parametrize("order,weight,col_block,ratio", [(4, 128, 256, 0.5), (0, 2048, 0, 1.0), (2, 512, 100000, 3.0)])
-def test_dense_hot_block_with_other_partition_knobs(cuda, monkeypatch, order, weight, col_block, ratio):
-    """The hot block next to every launch order / item weight / column-block setting of build_items."""
-    monkeypatch.setenv("TGCN_ITEM_ORDER", str(order))
+@pytest.mark.parametrize("weight,col_block,ratio", [(128, 256, 0.5), (2048, 0, 1.0), (512, 100000, 3.0)])
+def test_dense_hot_block_with_other_partition_knobs(cuda, monkeypatch, weight, col_block, ratio):
+    """The hot block next to other item weight / column-block settings of build_items."""
     monkeypatch.setenv("TGCN_ITEM_WEIGHT", str(weight))
     monkeypatch.setenv("TGCN_COL_BLOCK", str(col_block))
     monkeypatch.setenv("TGCN_HOT_RATIO", str(ratio))
     n = 6007
-    gen = torch.Generator().manual_seed(order + weight)
+    gen = torch.Generator().manual_seed(weight)
     ei, w = _hub_graph(n, 36, gen, dup=True)
     plan = GraphPlan(ei.to(cuda), w.to(cuda), n)
     assert plan.stats()["hot_rows"] > 0

@@ -2,7 +2,7 @@
 """Experiment driver for the SpMM kernel on config c4 (run on the GPU box).
 
   python tools/sweep_spmm.py phases          word rows vs document rows, timed separately
-  python tools/sweep_spmm.py variants        kernel variants (TGCN_SPMM_VARIANT) / item weights,
+  python tools/sweep_spmm.py variants        item weights / column blocks,
                                              one subprocess per setting (the knobs are read once)
 """
 import json
@@ -71,7 +71,7 @@ if __name__ == "__main__":
         phases()
     elif mode == "variants":
         settings = [dict(TGCN_LIB_PATH=os.path.join(ROOT, "pytextgcn_amd/lib/libtgcn_old.so")), dict(),
-                    dict(TGCN_SPMM_VARIANT="8:0"), dict(TGCN_COL_BLOCK="4096"), dict(TGCN_COL_BLOCK="16384"),
+                    dict(TGCN_COL_BLOCK="4096"), dict(TGCN_COL_BLOCK="16384"),
                     dict(TGCN_ITEM_WEIGHT="1024"), dict(TGCN_ITEM_WEIGHT="384")]
         for kv in settings:
             env = dict(os.environ, **kv)
