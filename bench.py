@@ -197,19 +197,36 @@ def device_copy_gbps(dev, n_bytes=1 << 30, reps=10):
     return 2.0 * n_bytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
 
 
+SPMM_KERNEL_SOURCES = ("pytextgcn_amd/csrc/spmm.hip", "pytextgcn_amd/csrc/plan.hip", "pytextgcn_amd/csrc/common.h")
+
+
+def spmm_kernel_sha16():
+    """Fingerprint of the sources that decide what one tgcn_spmm launch moves: the counter figures of
+    profiles/traffic.json are valid for the library they were collected on and no other."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SPMM_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def fabric_traffic(config, n_gpus):
     """L2 <-> fabric bytes per SpMM launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
     2*FETCH_SIZE + WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md 'HBM' prescribes).  Returns
-    (bytes, provenance) or (None, None).  NOT measured by this run: a constant from the named profile."""
+    (bytes, provenance, fresh) or (None, None, False).  NOT measured by this run: a constant from the named profile;
+    `fresh` says whether it was collected on THESE kernel sources (its `kernel_sha16` against spmm_kernel_sha16())."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f).get(f"{config}_n{n_gpus}", {})
         if "bytes_per_launch" in rec:
-            return rec["bytes_per_launch"], f"profiles/traffic.json[{config}_n{n_gpus}] ({rec.get('round', '?')})"
+            fresh = rec.get("kernel_sha16") == spmm_kernel_sha16()
+            return (rec["bytes_per_launch"], f"profiles/traffic.json[{config}_n{n_gpus}] ({rec.get('round', '?')})",
+                    fresh)
     except (OSError, ValueError):
         pass
-    return None, None
+    return None, None, False
 
 
 def profile_constant(key):
@@ -675,31 +692,40 @@ def main():
         per_s = 1.0 / (launch_ms * 1e-3) / 1e9
         n_out = N if parallelism == "single" else sg.n_local
         compulsory = 8 * plan.nnz + 4 * n_out + 8 * n_out * F if parallelism == "single" else None
-        fabric, fabric_src = fabric_traffic(args.config, world)
+        fabric, fabric_src, fabric_fresh = fabric_traffic(args.config, world)
         hbm_bytes = None
         if hbm and "bytes_per_step" in hbm:
             hbm_bytes = hbm["bytes_per_step"] / 2.0            # a step is two launches (forward, transposed)
-        if hbm_bytes is not None:
-            frac, frac_basis = hbm_bytes * per_s / HBM_PEAK_GBPS, "hbm bytes measured live (memory-controller activity)"
+        # `frac`: counter traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this bench command, committed under
+        # profiles/) when it was collected on these very kernel sources -- basis "fabric": what crosses the L2 <->
+        # Infinity Cache / HBM link, the link this kernel is bound by; otherwise the live memory-controller figure --
+        # basis "hbm".  Both are always reported side by side (frac_fabric, frac_hbm).
+        frac_fabric = None if fabric is None else fabric * per_s / HBM_PEAK_GBPS
+        frac_hbm = None if hbm_bytes is None else hbm_bytes * per_s / HBM_PEAK_GBPS
+        if fabric is not None and fabric_fresh:
+            frac, frac_basis, traffic, traffic_basis = frac_fabric, "fabric", fabric, fabric_src
+        elif hbm_bytes is not None:
+            frac, frac_basis, traffic = frac_hbm, "hbm", hbm_bytes
+            traffic_basis = "live: sysfs mem_busy_percent while the step loops, calibrated on a 1 GiB device copy"
         elif fabric is not None:
-            frac, frac_basis = fabric * per_s / HBM_PEAK_GBPS, "fabric counter bytes from " + fabric_src + " (upper bound on HBM)"
+            frac, frac_basis, traffic, traffic_basis = frac_fabric, "fabric-stale", fabric, fabric_src + " (older kernels)"
         else:
-            frac, frac_basis = min(achieved / HBM_PEAK_GBPS, 1.0), "algorithmic bytes, capped (no traffic measurement on file)"
+            frac, frac_basis, traffic, traffic_basis = min(achieved / HBM_PEAK_GBPS, 1.0), "algorithmic-capped", None, None
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": frac, "frac_basis": frac_basis,
-            "traffic": hbm_bytes if hbm_bytes is not None else fabric,
-            "traffic_basis": ("live: sysfs mem_busy_percent while the step loops, calibrated on a 1 GiB device copy"
-                              if hbm_bytes is not None else fabric_src),
+            "traffic": traffic, "traffic_basis": traffic_basis,
             "hbm_activity": hbm,
             "frac_algorithmic": achieved / HBM_PEAK_GBPS,
-            "traffic_fabric": fabric, "traffic_fabric_source": fabric_src,
-            "frac_traffic": None if fabric is None else fabric * per_s / HBM_PEAK_GBPS,
+            "frac_hbm": frac_hbm,
+            "frac_fabric": frac_fabric,
+            "traffic_fabric": fabric, "traffic_fabric_source": fabric_src, "traffic_fabric_fresh": fabric_fresh,
             "compulsory_bytes_per_launch": compulsory,
             "frac_compulsory": None if compulsory is None else compulsory * per_s / HBM_PEAK_GBPS,
             "l2_resident_ceiling_ms": profile_constant(f"{args.config}_F{F}_l2_resident_ceiling_ms"),
-            "kernel": "one tgcn_spmm launch: k_spmm_gather (+ k_spmm_hot, k_spmm_sweep, k_spmm_fix)" if parallelism == "single"
-                      else "one distributed SpMM on this rank: local SpMM launches + RCCL all-gather / reduce-scatter",
+            "kernel": ("one tgcn_spmm launch: k_spmm_gather" + (" + k_spmm_hot" if plan.stats().get("hot_rows") else "")
+                       + " + k_spmm_fix") if parallelism == "single"
+                      else "one distributed SpMM on this rank: local SpMM launches + the exchange",
             # secondary denominator: this box's device-to-device copy rate (read + write)
             "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
             # the measured HBM rate of the launch against what a plain copy reaches on THIS box

@@ -109,6 +109,35 @@ def main():
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
     print(json.dumps(out))
+    key = os.environ.get("TGCN_TRAFFIC_KEY")          # e.g. c4_n1: record the counter traffic for bench.py
+    if key and "fetch_kib" in out:
+        update_traffic(key, tag, out)
+
+
+def update_traffic(key, tag, out):
+    """profiles/traffic.json[key] <- bytes per tgcn_spmm launch = sum over its kernels of (2 * FETCH_SIZE + WRITE_SIZE),
+    stamped with the fingerprint of the kernel sources it was collected on (bench.py: spmm_kernel_sha16)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    kernels = sorted(set(out["fetch_kib"]) | set(out["write_kib"]))
+    fetch = {k.split("<")[0]: out["fetch_kib"].get(k, 0.0) for k in kernels}
+    write = {k.split("<")[0]: out["write_kib"].get(k, 0.0) for k in kernels}
+    total = sum(2.0 * fetch[k] + write[k] for k in fetch) * 1024.0
+    path = os.path.join(HERE, "traffic.json")
+    with open(path) as f:
+        db = json.load(f)
+    db[key] = {
+        "bytes_per_launch": total,
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the bench command (tools/"
+                  "collect_evidence.sh); per tgcn_spmm launch = sum over its kernels; bytes = (2*FETCH_SIZE + WRITE_SIZE)"
+                  " KiB * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM' (calibration of round 1, profiles/"
+                  "calibrate_fetch.py). Counts L2<->fabric requests, Infinity-Cache hits included: an upper bound on HBM "
+                  "bytes (the live HBM figure is bench.py's roofline.hbm_activity).",
+        "fetch_size_kib": fetch, "write_size_kib": write, "round": tag,
+        "kernel_sha16": bench.spmm_kernel_sha16()}
+    with open(path, "w") as f:
+        json.dump(db, f, indent=1)
+    print(f"profiles/traffic.json[{key}] = {total / 1e9:.3f} GB per launch ({tag}, kernels {db[key]['kernel_sha16']})")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,11 @@
 """Synthetic TextGCN-shaped graphs; the real Amazon / DBpedia CSVs are
 absent from the reference tree (.MISSING_LARGE_BLOBS:1-3), so every benchmark and large parity
-case is generated here.  Deterministic for a given (seed, device type); written in torch so that
-the 50 M-edge configuration is built on the GPU in seconds and the small ones on the CPU.
+case is generated here.  Deterministic for a given seed WHATEVER the device: every random number is
+drawn from a CPU `torch.Generator` (torch's mt19937 stream, the same on every machine) and moved
+to `device`, where only deterministic work happens (searches, sorts, de-duplication) -- so the
+50 M-edge configuration is still built on the GPU in seconds, and a graph generated there is the one
+a CPU-only host regenerates from the same seed.  (SURVEY.md 8(d) names numpy's default_rng(44); the
+torch CPU generator plays that role: seed 44, no device-dependent stream.)
 
 Layout reproduced from textgcn/lib/text2graph.py:
   * node numbering: words [0, V), documents [V, V + D)                       (:169-170,183,191)
@@ -22,13 +26,26 @@ from .data import Data
 
 
 def _zipf_cdf(V: int, s: float, device) -> torch.Tensor:
-    p = torch.arange(1, V + 1, dtype=torch.float64, device=device).pow_(-s)
+    p = torch.arange(1, V + 1, dtype=torch.float64).pow_(-s)     # on the host: a device scan may round differently
     cdf = torch.cumsum(p, 0)
-    return (cdf / cdf[-1]).float()
+    return (cdf / cdf[-1]).float().to(device)
+
+
+def _rand(n: int, gen: torch.Generator, device) -> torch.Tensor:
+    """n uniform floats in [0, 1) from the CPU stream, on `device`."""
+    return torch.rand(n, generator=gen).to(device)
+
+
+def _randint(hi: int, n: int, gen: torch.Generator, device) -> torch.Tensor:
+    return torch.randint(0, hi, (n,), generator=gen).to(device)
+
+
+def _randperm(n: int, gen: torch.Generator, device) -> torch.Tensor:
+    return torch.randperm(n, generator=gen).to(device)
 
 
 def _sample(cdf: torch.Tensor, n: int, gen: torch.Generator) -> torch.Tensor:
-    u = torch.rand(n, generator=gen, device=cdf.device)
+    u = _rand(n, gen, cdf.device)
     return torch.searchsorted(cdf, u).clamp_(max=cdf.numel() - 1)
 
 
@@ -36,7 +53,7 @@ def _pick(keys: torch.Tensor, n: int, gen: torch.Generator) -> torch.Tensor:
     """n of the (unique, sorted) keys, chosen at random, returned sorted."""
     if keys.numel() == n:
         return keys
-    sel = torch.randperm(keys.numel(), generator=gen, device=keys.device)[:n]
+    sel = _randperm(keys.numel(), gen, keys.device)[:n]
     return keys[sel].sort().values
 
 
@@ -47,7 +64,7 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
     if n_edges % 2:
         raise ValueError("n_edges must be even (every edge is emitted in both directions)")
     device = torch.device(device)
-    gen = torch.Generator(device=device)
+    gen = torch.Generator()                    # CPU stream: the graph does not depend on where it is built
     gen.manual_seed(seed)
     V = max(2, int(n_nodes * vocab_frac))
     D = n_nodes - V
@@ -62,7 +79,7 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
     if n_dw > D * V:
         raise ValueError("graph too dense for the requested shape")
     cdf = _zipf_cdf(V, zipf_s, device)
-    word_perm = torch.randperm(V, generator=gen, device=device)   # vocabulary order is not rank order
+    word_perm = _randperm(V, gen, device)      # vocabulary order is not rank order
 
     # ---- document-word incidences: k_d ~ clip(LogNormal, 4, 400) distinct Zipf words per doc ----
     keys = torch.empty(0, dtype=torch.int64, device=device)
@@ -74,14 +91,14 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
             mean = max(1.0, 1.25 * want / D)
             sigma = 0.8
             mu = math.log(mean) - 0.5 * sigma * sigma
-            k = torch.empty(D, device=device).log_normal_(mu, sigma, generator=gen)
+            k = torch.empty(D).log_normal_(mu, sigma, generator=gen).to(device)
             k = k.clamp_(min(4.0, mean), 400.0).round_().long().clamp_(max=V)
             docs = torch.repeat_interleave(torch.arange(D, device=device), k)
             words = word_perm[_sample(cdf, docs.numel(), gen)]
         else:                                  # very dense requests: top up uniformly
             m = 2 * want + 16
-            docs = torch.randint(0, D, (m,), generator=gen, device=device)
-            words = torch.randint(0, V, (m,), generator=gen, device=device)
+            docs = _randint(D, m, gen, device)
+            words = _randint(V, m, gen, device)
         keys = torch.unique(torch.cat([keys, docs * V + words]))
         want = max(n_dw - keys.numel(), 1)
     if keys.numel() < n_dw:
@@ -99,8 +116,8 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
         if round_ < 48:
             a, b = word_perm[_sample(cdf, m, gen)], word_perm[_sample(cdf, m, gen)]
         else:
-            a = torch.randint(0, V, (m,), generator=gen, device=device)
-            b = torch.randint(0, V, (m,), generator=gen, device=device)
+            a = _randint(V, m, gen, device)
+            b = _randint(V, m, gen, device)
         ok = a != b
         lo, hi = torch.minimum(a, b)[ok], torch.maximum(a, b)[ok]
         keys = torch.unique(torch.cat([keys, lo * V + hi]))
@@ -112,10 +129,11 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
 
     # ---- weights --------------------------------------------------------------------------------
     # PMI-like: Exp(1) clipped to (1e-10, 12]; TF-IDF-like: u / ||u||_2 per document, u ~ U(0.05, 1]
-    w_ww = torch.empty(n_ww, device=device).exponential_(1.0, generator=gen).clamp_(1e-10, 12.0)
-    u = torch.rand(n_dw, generator=gen, device=device) * 0.95 + 0.05
-    sq = torch.zeros(D, device=device).index_add_(0, dw_doc, u * u)
-    w_dw = u / sq.sqrt()[dw_doc]
+    w_ww = torch.empty(n_ww).exponential_(1.0, generator=gen).to(device).clamp_(1e-10, 12.0)
+    u = _rand(n_dw, gen, device) * 0.95 + 0.05
+    # per-document norms on the host in float64 (a device index_add_ adds in atomic, i.e. varying, order)
+    sq = torch.zeros(D, dtype=torch.float64).index_add_(0, dw_doc.cpu(), (u.cpu().double()) ** 2)
+    w_dw = u / sq.sqrt().float().to(device)[dw_doc]
 
     coo = torch.empty(n_edges, 2, dtype=torch.int64, device=device)
     coo[0:2 * n_ww:2, 0], coo[0:2 * n_ww:2, 1] = ww_i, ww_j
@@ -128,8 +146,8 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
     # ---- labels, masks, features ---------------------------------------------------------------
     N = n_nodes
     y = torch.zeros(N, dtype=torch.int64, device=device)
-    y[V:] = torch.randint(0, n_classes, (D,), generator=gen, device=device)
-    order = torch.randperm(D, generator=gen, device=device) + V
+    y[V:] = _randint(n_classes, D, gen, device)
+    order = _randperm(D, gen, device) + V
     n_test, n_val = D // 10, D // 10
     masks = [torch.zeros(N, dtype=torch.bool, device=device) for _ in range(3)]
     masks[0][order[:n_test]] = True
@@ -156,13 +174,13 @@ def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", al
     `n_classes` > 0 adds uniform labels and 80/10/10 masks over ALL nodes (there are no word nodes here);
     `features="sparse_identity"` the one-hot feature matrix of text2graph.py:179."""
     device = torch.device(device)
-    gen = torch.Generator(device=device)
+    gen = torch.Generator()                    # CPU stream (see the module docstring)
     gen.manual_seed(seed)
     N = n_nodes
-    uu = torch.rand(N, generator=gen, device=device).clamp_(min=1e-12)
-    deg_w = uu.pow(-1.0 / (alpha - 1.0)).clamp_(1.0, 1e6).double()      # inverse-CDF Pareto
+    uu = _rand(N, gen, device).clamp_(min=1e-12)
+    deg_w = uu.cpu().double().pow(-1.0 / (alpha - 1.0)).clamp_(1.0, 1e6)  # inverse-CDF Pareto; host scan (see _zipf_cdf)
     cdf = torch.cumsum(deg_w, 0)
-    cdf = (cdf / cdf[-1]).float()
+    cdf = (cdf / cdf[-1]).float().to(device)
     n_pairs = n_edges // 2 if symmetric else n_edges
     keys = torch.empty(0, dtype=torch.int64, device=device)
     want = n_pairs
@@ -173,8 +191,8 @@ def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", al
         if round_ < 48:
             a, b = _sample(cdf, m, gen), _sample(cdf, m, gen)
         else:
-            a = torch.randint(0, N, (m,), generator=gen, device=device)
-            b = torch.randint(0, N, (m,), generator=gen, device=device)
+            a = _randint(N, m, gen, device)
+            b = _randint(N, m, gen, device)
         ok = a != b
         a, b = a[ok], b[ok]
         if symmetric:
@@ -183,7 +201,7 @@ def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", al
         want = max(n_pairs - keys.numel(), 1)
     keys = _pick(keys, n_pairs, gen)
     a, b = keys // N, keys % N
-    w = 1.0 - torch.rand(n_pairs, generator=gen, device=device)
+    w = 1.0 - _rand(n_pairs, gen, device)
     if symmetric:
         coo = torch.empty(2 * n_pairs, 2, dtype=torch.int64, device=device)
         coo[0::2, 0], coo[0::2, 1] = a, b
@@ -193,8 +211,8 @@ def power_law_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", al
         coo = torch.stack([a, b], 1)
     g = Data(x=None, edge_index=coo.T, edge_attr=w.float(), n_vocab=0)
     if n_classes > 0:
-        g.y = torch.randint(0, n_classes, (N,), generator=gen, device=device)
-        u = torch.rand(N, generator=gen, device=device)
+        g.y = _randint(n_classes, N, gen, device)
+        u = _rand(N, gen, device)
         g.train_mask, g.val_mask, g.test_mask = u < 0.8, (u >= 0.8) & (u < 0.9), u >= 0.9
         g.n_classes = n_classes
     if features == "sparse_identity":

@@ -446,6 +446,16 @@ def test_error_behaviour(cuda):
     assert torch.equal(cs, torch.zeros(5, device=cuda))                      # no rows: the sums are zero, not stale
 
 
+def test_synthetic_graphs_do_not_depend_on_the_device_they_are_built_on(cuda):
+    """pytextgcn_amd.synth draws every random number from a CPU generator: the graph built on the GPU (what bench.py
+    and the large parity cases use) is bit for bit the graph a CPU-only host builds from the same seed."""
+    for make in (lambda d: synth.word_doc_graph(60_000, 1_200_000, seed=44, device=d, n_classes=9),
+                 lambda d: synth.power_law_graph(50_000, 900_000, seed=44, device=d, n_classes=4)):
+        a, b = make("cpu"), make(cuda)
+        assert torch.equal(a.edge_index, b.edge_index.cpu()) and torch.equal(a.edge_attr, b.edge_attr.cpu())
+        assert torch.equal(a.y, b.y.cpu()) and torch.equal(a.train_mask, b.train_mask.cpu())
+
+
 # ------------------------------------------------------------------------------------------------
 # benchmark-sized inputs (BASELINE.json configs c2 and c4)
 # ------------------------------------------------------------------------------------------------
@@ -1425,7 +1435,9 @@ def test_one_plan_on_two_streams_and_two_threads(cuda):
 
 @pytest.mark.parametrize("F", [200, 64, 6])
 def test_split_operand_spmm(cuda, F):
-    """tgcn_spmm_split: columns [0, split) from one buffer, the rest from another (sharded path)."""
+    """tgcn_spmm_split: columns [0, split) from one buffer, the rest from another (the sharded path at wide widths).
+    Bit for bit the single-buffer result where the same kernel serves both (F > 128 and the scalar path); at narrow
+    widths the single buffer takes the sub-group kernel and the split operand the full-wave one: another order."""
     g = synth.random_graph(900, 12000, seed=31, self_loops=4, duplicates=9)
     ei, w = g.edge_index.to(cuda), g.edge_attr.to(cuda)
     plan = GraphPlan(ei, w, 900)
@@ -1435,7 +1447,11 @@ def test_split_operand_spmm(cuda, F):
     for split in (0, 1, 333, 899):
         a, c = x[:split].clone(), torch.randn(1200, F, device=cuda)
         c[77:77 + 900 - split] = x[split:]
-        assert torch.equal(plan.spmm(a, b, x2=c[77:77 + 900 - split]), ref), split
+        got = plan.spmm(a, b, x2=c[77:77 + 900 - split])
+        if (F > 128 or F % 4 != 0) and 0 < split:
+            assert torch.equal(got, ref), split
+        else:
+            assert rel_err(got, ref) < 1e-6, split
     with pytest.raises(ValueError):
         plan.spmm(x[:10], b, x2=x[:5])
 
@@ -1641,7 +1657,11 @@ def test_dense_hot_block_matches_oracle_and_gather_path(cuda, monkeypatch, n, n_
             split = n // 3
             hi = torch.randn(n, F, device=cuda)
             hi[11:11 + n - split] = xd[split:]
-            assert torch.equal(plan.spmm(xd[:split].clone(), bd, x2=hi[11:11 + n - split]), plan.spmm(xd, bd))
+            got_split = plan.spmm(xd[:split].clone(), bd, x2=hi[11:11 + n - split])
+            if F > 128:      # the full-wave kernel serves both forms: same sums in the same order
+                assert torch.equal(got_split, plan.spmm(xd, bd))
+            else:            # narrow widths: one buffer -> sub-group kernel, split operand -> full-wave kernel
+                assert rel_err(got_split, plan.spmm(xd, bd)) < 1e-6
             out = torch.full((n, F + 12), 7.0, device=cuda)
             plan.spmm(xd, bd, out=out[:, 4:4 + F])
             assert torch.equal(out[:, 4:4 + F], plan.spmm(xd, bd)) and bool((out[:, :4] == 7).all())

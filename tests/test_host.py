@@ -286,3 +286,22 @@ def test_build_refuses_spills_in_the_asm_ring_kernels():
         build.check_asm_ring_kernels(remark(ring, 0, 0) + remark(split, 0, 2))
     with pytest.raises(RuntimeError, match="no kernel-resource-usage remarks"):
         build.check_asm_ring_kernels(remark(loop, 0, 0))
+
+
+def test_counter_traffic_on_file_belongs_to_the_current_kernels():
+    """bench.py quotes the L2 <-> fabric bytes of one tgcn_spmm launch from profiles/traffic.json, a constant collected
+    with rocprofv3 counters.  It is only valid for the kernels it was collected on: the record carries a fingerprint
+    of csrc/spmm.hip + plan.hip + common.h, and this test fails when those sources have changed since (re-run
+    tools/collect_evidence.sh on the GPU box and commit the new profile)."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(root, "profiles", "traffic.json")))["c4_n1"]
+    assert rec.get("kernel_sha16") == bench.spmm_kernel_sha16(), \
+        "profiles/traffic.json[c4_n1] predates the last change of the SpMM kernels: collect the counters again"
+    b, src, fresh = bench.fabric_traffic("c4", 1)
+    assert fresh and b == rec["bytes_per_launch"] and 1e9 < b < 1e11
