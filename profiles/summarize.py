@@ -84,14 +84,20 @@ def main():
     out = {"tag": tag}
     if len(sys.argv) >= 5:
         fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
-        lines += ["", "## PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE, KiB per dispatch", "",
-                  "| kernel | counter | dispatches | mean KiB | min | max |", "|---|---|---|---|---|---|"]
+        lines += ["", "## PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE in KiB per dispatch (TCC_* in requests)", "",
+                  "| kernel | counter | dispatches | mean | min | max |", "|---|---|---|---|---|---|"]
         for agg in (fe, wr):
             for (k, c), v in sorted(agg.items()):
                 if "spmm" in k or "colsum" in k:
                     lines.append(f"| `{k}` | {c} | {len(v)} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} |")
-        out["fetch_kib"] = {k: sum(v) / len(v) for (k, c), v in fe.items() if "spmm" in k}
-        out["write_kib"] = {k: sum(v) / len(v) for (k, c), v in wr.items() if "spmm" in k}
+        out["fetch_kib"] = {k: sum(v) / len(v) for (k, c), v in fe.items() if "spmm" in k and c == "FETCH_SIZE"}
+        out["write_kib"] = {k: sum(v) / len(v) for (k, c), v in wr.items() if "spmm" in k and c == "WRITE_SIZE"}
+        hits = {k: sum(v) / len(v) for (k, c), v in wr.items() if "spmm" in k and c == "TCC_HIT_sum"}
+        miss = {k: sum(v) / len(v) for (k, c), v in wr.items() if "spmm" in k and c == "TCC_MISS_sum"}
+        if hits:
+            out["l2_hit_rate"] = {k: hits[k] / (hits[k] + miss[k]) for k in hits if k in miss and hits[k] + miss[k] > 0}
+            lines += ["", "L2 hit rate (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)): " +
+                      ", ".join(f"`{k}` {v:.3f}" for k, v in sorted(out["l2_hit_rate"].items()))]
     if len(sys.argv) >= 7:
         lines += ["", "## Calibration on a known byte count (profiles/calibrate_fetch.py: permutation "
                   "operator, N = 4 M, F = 200)", ""]

@@ -56,12 +56,12 @@ class GCN(nn.Module):
         tail = [None] * len(layers)            # tail[i] = W_{i+1} ... W_L (None = identity)
         for i in range(len(layers) - 2, -1, -1):
             w_next = layers[i + 1].weight
-            tail[i] = w_next if tail[i + 1] is None else w_next @ tail[i + 1]
+            tail[i] = w_next if tail[i + 1] is None else dense.xw(w_next, tail[i + 1])
         z = layers[0].features_times(g.x, dense.xw(layers[0].weight, tail[0]))
         for i, layer in enumerate(layers):
             b = layer.bias
             if b is not None and tail[i] is not None:
-                b = b @ tail[i]
+                b = dense.xw(b.unsqueeze(0), tail[i]).squeeze(0)      # a 1-row product: still no vendor GEMM
             z = propagate(layer.plan(g.x, g.edge_index, g.edge_attr), z, b)
         return z
 
