@@ -400,12 +400,11 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
     return t.item()
 
 
-def exchange_diagnostics(sg, F, dev, dist, reps=10, extra=False):
+def exchange_diagnostics(sg, F, dev, dist, reps=10):
     """N > 1 only, outside the timed region: where one distributed SpMM spends its time on THIS node.
     Every phase is timed on its own (barrier + sync on both sides, max over ranks): the two local
-    operators, the two RCCL collectives of pytextgcn_amd.sharded, and an all-to-all formulation of the
-    reduce-scatter (all_to_all_single + local sum) for comparison.  A phase that raises is reported as
-    null; nothing here feeds `value`."""
+    operators, the two RCCL collectives, the halo form's gather of the referenced rows, and the overlapped whole
+    in the form the bench chose.  A phase that raises is reported as an error string; nothing here feeds `value`."""
     A, B = sg.ops[0]
     W, hp, rp = sg.world, sg.hp, sg.rp
     gen = torch.Generator(device=dev).manual_seed(99)
@@ -413,7 +412,6 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10, extra=False):
     xbuf = torch.empty(W * hp, F, device=dev)
     partial = torch.randn(W * hp, F, device=dev, generator=gen)
     rs_out = torch.empty(hp, F, device=dev)
-    a2a = torch.empty(W * hp, F, device=dev)
 
     def phase(fn):
         try:
@@ -434,45 +432,22 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10, extra=False):
             return {"error": f"{type(e).__name__}: {e}"[:200]}
 
     out = {"bytes_each_way_per_collective": int((W - 1) * hp * F * 4)}
-    if not extra:
-        # only what the timed region itself uses: these go into the bench line
-        if A is not None:
-            out["local_A_hub_rows_x_own_regulars"] = phase(lambda: A.spmm(x[hp:]))
-        out["local_B_own_rows"] = phase(lambda: B.spmm(xbuf, None, x2=x[hp:] if rp > 0 else None))
-        out["all_gather_into_tensor"] = phase(lambda: dist.all_gather_into_tensor(xbuf, x[:hp].contiguous()))
-        out["reduce_scatter_tensor"] = phase(lambda: dist.reduce_scatter_tensor(rs_out, partial))
-        d0 = sg.dirs[0]
-        direct = sg._stream_ordered(x)
+    if A is not None:
+        out["local_A_hub_rows_x_own_regulars"] = phase(lambda: A.spmm(x[hp:]))
+    out["local_B_own_rows"] = phase(lambda: B.spmm(xbuf, None, x2=x[hp:] if rp > 0 else None))
+    out["all_gather_into_tensor"] = phase(lambda: dist.all_gather_into_tensor(xbuf, x[:hp].contiguous()))
+    out["reduce_scatter_tensor"] = phase(lambda: dist.reduce_scatter_tensor(rs_out, partial))
+    d0 = sg.dirs[0]
+    direct = sg._stream_ordered(x)
 
-        def halo_gather():
-            pack = x[:hp].index_select(0, d0.send_slots)
-            recv, work = sg._all_to_all_v(pack, d0.need_counts_l, d0.send_counts_l, direct)
-            work.wait()
-            xbuf.index_copy_(0, d0.need_cols, recv)
-        out["halo_gather_referenced_rows_only"] = phase(halo_gather)
-        out["rows_received_per_spmm"] = sg.exchange_rows()
-        out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
-        return out
-
-    # alternative exchange formulations (communication patterns the timed region does not use): run
-    # AFTER the bench line is out, reported on stderr
-    def rs_by_all_to_all():
-        dist.all_to_all_single(a2a, partial)
-        torch.sum(a2a.view(W, hp, F), dim=0, out=rs_out)
-    out["reduce_scatter_as_all_to_all_plus_sum"] = phase(rs_by_all_to_all)
-
-    def ag_by_p2p():                                  # every shard sent straight to every peer (7 links at once)
-        shard = x[:hp].contiguous()
-        ops = []
-        for q in range(W):
-            if q != sg.rank:
-                ops.append(dist.P2POp(dist.isend, shard, q))
-                ops.append(dist.P2POp(dist.irecv, xbuf[q * hp:(q + 1) * hp], q))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        xbuf[sg.rank * hp:(sg.rank + 1) * hp].copy_(shard)
-    out["all_gather_as_batched_p2p"] = phase(ag_by_p2p)
+    def halo_gather():
+        pack = x[:hp].index_select(0, d0.send_slots)
+        recv, work = sg._all_to_all_v(pack, d0.need_counts_l, d0.send_counts_l, direct)
+        work.wait()
+        xbuf.index_copy_(0, d0.need_cols, recv)
+    out["halo_gather_referenced_rows_only"] = phase(halo_gather)
+    out["rows_received_per_spmm"] = sg.exchange_rows()
+    out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
     return out
 
 
@@ -620,16 +595,24 @@ def main():
             sg.set_rs_chunks(K)
             for mode in forms:
                 sg.exchange = mode
-                step()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(3):
+                try:                       # a form this backend / build refuses raises on every rank alike: skip it
                     step()
-                barrier()
-                t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=dev, dtype=torch.float64)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    barrier()
+                    ms = (time.perf_counter() - t0) / 3 * 1e3
+                except RuntimeError as e:
+                    print(f"bench.py: exchange form {mode}/{K} failed on rank {rank}: {e}"[:300], file=sys.stderr, flush=True)
+                    ms = float("inf")
+                t = torch.tensor([ms], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[f"{mode}/{K}"] = t.item()
         best = min(trial, key=trial.get)
+        if trial[best] == float("inf"):
+            raise RuntimeError(f"no form of the exchange works on this node: {trial}")
+        trial = {k: (v if v != float("inf") else None) for k, v in trial.items()}
         sg.exchange = best.split("/")[0]
         sg.set_rs_chunks(int(best.split("/")[1]))
         exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows()}
@@ -771,10 +754,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or force_sharded:
-        more = exchange_diagnostics(sg, F, dev, dist, extra=True)
-        if rank == 0:
-            print(json.dumps({"exchange_diagnostics_extra": more, "n_gpus": world}), file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

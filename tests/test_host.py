@@ -305,3 +305,25 @@ def test_counter_traffic_on_file_belongs_to_the_current_kernels():
         "profiles/traffic.json[c4_n1] predates the last change of the SpMM kernels: collect the counters again"
     b, src, fresh = bench.fabric_traffic("c4", 1)
     assert fresh and b == rec["bytes_per_launch"] and 1e9 < b < 1e11
+
+
+def test_committed_round3_bench_line_names_the_basis_of_its_roofline_fraction():
+    """profiles/r03_bench_c4_n1.json: `roofline.frac` is the counter traffic of profiles/traffic.json (collected on the
+    same kernel sources) over the live launch time over the peak, `frac_basis` says so in one word, and the HBM,
+    algorithmic and compulsory fractions stand beside it; no kernel is named that did not run."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r03_bench_c4_n1.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 50_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["frac_basis"] == "fabric" and r["traffic_fabric_fresh"] is True
+    assert abs(r["frac"] - r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-6 and 0 < r["frac"] <= 1.0
+    assert r["frac_compulsory"] < r["frac_hbm"] < r["frac_fabric"] <= 1.0 < r["frac_algorithmic"]
+    assert "sweep" not in r["kernel"] and "k_spmm_gather" in r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["csr"]["value"] > c["value"] > 0
