@@ -16,7 +16,7 @@ import torch
 from torch import Tensor, nn
 
 from . import dense
-from .plan import GraphPlan, colsum, plan_for
+from .plan import GraphPlan, colsum, padded_base, plan_for
 
 
 def _fused_optimizer_for(param):
@@ -27,6 +27,13 @@ def _fused_optimizer_for(param):
 def _pad_cols(t: Tensor, width: int) -> Tensor:
     if t.size(-1) == width:
         return t
+    if t.dim() == 1:                            # a bias: `width` floats
+        out = t.new_zeros(width)
+        out[:t.numel()] = t
+        return out
+    base = padded_base(t, width)               # a producer of this package left it padded: no copy
+    if base is not None:
+        return base
     return torch.nn.functional.pad(t, (0, width - t.size(-1)))
 
 

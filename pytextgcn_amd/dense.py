@@ -9,7 +9,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .plan import _stream_ptr
+from .plan import _stream_ptr, alloc_padded
 
 
 def enable_split_gemms(on: bool = True) -> bool:
@@ -52,7 +52,7 @@ def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(1)
-    c = torch.empty(N, n, dtype=torch.float32, device=a.device)
+    c = alloc_padded(N, n, a.device)          # rows of 4 j floats (zero pad columns): the propagate step takes it as it is
     args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
     if seed is None:
         _lib.check(lib.tgcn_gemm_nn(*args, _stream_ptr(a.device)))

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .plan import _require_cuda, _stream_ptr, note_colsum
+from .plan import _require_cuda, _stream_ptr, alloc_padded, note_colsum, padded_base
 
 _COUNT_CACHE: dict = {}
 
@@ -87,13 +87,17 @@ def _launch(logits: Tensor, target: Tensor, mask: Tensor, want_grad: bool, count
     pred = torch.empty(n, dtype=torch.int64, device=logits.device) if want_pred else None
     if want_grad:
         # loss, gradient and the column sums of the gradient (the last layer's bias gradient) in one pass
-        dlogits = torch.empty(n, C, dtype=torch.float32, device=logits.device)
-        dbias = torch.empty(C, dtype=torch.float32, device=logits.device)
+        # rows of 4 j floats (zero pad columns) when C is not a multiple of 4: the backward propagate step then takes the
+        # gradient as it is instead of padding a copy; its column sums are kept at the padded width for the same reason
+        dlogits = alloc_padded(n, C, logits.device)
+        C4 = (C + 3) & ~3
+        dbias = torch.zeros(C4, dtype=torch.float32, device=logits.device)[:C] if C4 != C else \
+            torch.empty(C, dtype=torch.float32, device=logits.device)
         ws_bytes = lib.tgcn_masked_ce_grad_workspace_bytes(n, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logits.device)
         _lib.check(lib.tgcn_masked_ce_grad(
             logits.data_ptr(), logits.stride(0), n, C, target.data_ptr(), mask.data_ptr(),
-            ctypes.c_float(inv), loss.data_ptr(), dlogits.data_ptr(), C, dbias.data_ptr(),
+            ctypes.c_float(inv), loss.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), dbias.data_ptr(),
             pred.data_ptr() if pred is not None else None,
             ws.data_ptr(), ws_bytes, _stream_ptr(logits.device)))
         return loss, (dlogits, dbias), pred
@@ -140,8 +144,12 @@ class _MaskedCE(torch.autograd.Function):
         else:
             dlogits.mul_(grad_out)
             dbias.mul_(grad_out)
-        # the layer that produced the logits finds its bias gradient ready (plan.colsum)
-        note_colsum(dlogits, dbias)
+        # the layer that produced the logits finds its bias gradient ready (plan.colsum) -- under the padded buffer too
+        base = padded_base(dlogits, (dlogits.size(1) + 3) & ~3)
+        if base is not None:                  # (view and buffer share one address: the note goes to the form that is asked for)
+            note_colsum(base, dbias._base if dbias._base is not None else dbias)
+        else:
+            note_colsum(dlogits, dbias)
         return dlogits, None, None, None, None
 
 

@@ -226,6 +226,39 @@ def _spmm_adam(self, g: Tensor, param: Tensor, exp_avg: Tensor, exp_avg_sq: Tens
 GraphPlan.spmm_adam = _spmm_adam
 
 
+# Row-padded buffers.  The float4 SpMM path wants rows of 4 k floats; a width that is not a multiple of 4 (DBpedia's 219
+# classes) used to be padded by a copy in front of every propagate step.  Producers inside this package (the nn GEMM,
+# the cross-entropy gradient) instead allocate their [n, F] result as the first F columns of a zero-padded [n, F4] buffer
+# and hand out the view; `padded_base` gives the propagate step the buffer back -- no copy.  Only this package ever holds
+# the base, and its kernels write the first F columns only, so the pad columns stay zero.
+_PADDED: dict = {}
+
+
+def alloc_padded(n: int, F: int, device) -> Tensor:
+    """A float32 [n, F] tensor that is the leading part of a zero-padded [n, round_up(F, 4)] buffer (a plain contiguous
+    tensor when F is a multiple of 4)."""
+    import weakref
+    F4 = (F + 3) & ~3
+    if F4 == F:
+        return torch.empty(n, F, dtype=torch.float32, device=device)
+    base = torch.empty(n, F4, dtype=torch.float32, device=device)
+    base[:, F:].zero_()
+    view = base[:, :F]
+    key = base.data_ptr()
+    _PADDED[key] = weakref.ref(base, lambda _, k=key: _PADDED.pop(k, None))
+    return view
+
+
+def padded_base(t: Tensor, width: int) -> Optional[Tensor]:
+    """The zero-padded [n, width] buffer `t` is the leading part of, if it came from `alloc_padded` (else None)."""
+    hit = _PADDED.get(t.data_ptr())
+    base = hit() if hit is not None else None
+    if base is None or t.dim() != 2 or base.shape != (t.size(0), width) or t.stride() != (width, 1) \
+            or base.data_ptr() != t.data_ptr() or t.dtype != torch.float32:
+        return None
+    return base
+
+
 # Column sums a producer kernel already took while it wrote the matrix (tgcn_masked_ce_grad: the gradient of the
 # logits; tgcn_gemm_nt*: the gradient of the hidden activation).  Keyed by storage address, validated by a weak
 # reference to the producing tensor (alive => the address was not recycled), its shape and its version counter.

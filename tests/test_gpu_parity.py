@@ -1170,6 +1170,35 @@ def test_fused_dropout_products_wider_than_one_lds_image(cuda, N, k, n, p):
     assert ((sums.double() - dx.double().sum(0)).abs().max() / dx.double().sum(0).abs().max()).item() < 2e-5
 
 
+@pytest.mark.parametrize("C", [219, 7, 64])
+def test_odd_class_width_needs_no_padding_copies_in_the_fused_step(cuda, monkeypatch, C):
+    """The float4 SpMM path wants rows of 4 j floats.  For a class count that is no multiple of 4 (DBpedia l3: 219)
+    the nn GEMM and the fused cross-entropy leave their results as the leading columns of zero-padded buffers
+    (plan.alloc_padded), so the propagate step needs no `pad` copy in either direction -- and the step still matches
+    the oracle, bias gradient (taken from the noted column sums of the padded gradient) included."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    N = 4000
+    g = synth.word_doc_graph(N, 60000, seed=5, n_classes=C)
+    torch.manual_seed(2)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=40, dropout=0.0)
+    mine = pkg.GCN(N, C, n_hidden_gcn=40, dropout=0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(cuda).float()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    lo_r = ref(g)
+    torch.nn.CrossEntropyLoss()(lo_r[g.train_mask], g.y[g.train_mask]).backward()
+
+    def no_pad(*a, **kw):
+        raise AssertionError("a padding copy was made")
+    monkeypatch.setattr(torch.nn.functional, "pad", no_pad)
+    lo_m = mine(gd)
+    masked_cross_entropy(lo_m, gd.y, gd.train_mask).backward()
+    monkeypatch.undo()
+    assert rel_err(lo_m, lo_r) < TOL
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad, pr.grad) < 5 * TOL, k
+
+
 def test_config_c3_sized_layer_two_runs_on_the_hand_written_kernels(cuda, monkeypatch):
     """GCN(N, 219, n_hidden_gcn=200) -- DBpedia l3's class count at BASELINE's hidden width (flat_dbpedia.py:80) --
     forward and backward against float64, with torch.matmul made to fail: no product of the model may reach
