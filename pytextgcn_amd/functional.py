@@ -137,17 +137,18 @@ class _MaskedCE(torch.autograd.Function):
             raise RuntimeError("masked_cross_entropy: backward was already run through this loss (its gradient "
                                "buffer is scaled in place); recompute the loss instead of retain_graph=True")
         ctx._tgcn_used = True
+        base = padded_base(dlogits, (dlogits.size(1) + 3) & ~3)       # the zero-padded buffer behind an odd class width
         if grad_out.is_cuda and grad_out.dtype == torch.float32 and grad_out.numel() == 1:
-            # `loss.backward()` seeds this node with 1: the kernel reads the scalar and leaves at once
-            _scale_by_device_scalar(dlogits, grad_out)
+            # `loss.backward()` seeds this node with 1: the kernel reads the scalar and leaves at once.  (The kernel
+            # walks a flat buffer: the padded one where there is one -- its pad columns are and stay zero.)
+            _scale_by_device_scalar(base if base is not None else dlogits, grad_out)
             _scale_by_device_scalar(dbias, grad_out)
         else:
             dlogits.mul_(grad_out)
             dbias.mul_(grad_out)
         # the layer that produced the logits finds its bias gradient ready (plan.colsum) -- under the padded buffer too
-        base = padded_base(dlogits, (dlogits.size(1) + 3) & ~3)
-        if base is not None:                  # (view and buffer share one address: the note goes to the form that is asked for)
-            note_colsum(base, dbias._base if dbias._base is not None else dbias)
+        if base is not None:                  # (view and buffer share one address: one note, under the padded form)
+            note_colsum(base, torch.as_strided(dbias, (base.size(1),), (1,)))     # dbias was cut from zeros(C4)
         else:
             note_colsum(dlogits, dbias)
         return dlogits, None, None, None, None

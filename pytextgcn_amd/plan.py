@@ -278,10 +278,15 @@ def _known_colsum(g: Tensor) -> Optional[Tensor]:
     if hit is None:
         return None
     t = hit[0]()
-    if t is None or t.data_ptr() != g.data_ptr() or hit[1] != tuple(g.shape) or hit[2] != g._version \
-            or t._version != g._version or not g.is_contiguous() or hit[3]._version != hit[4]:
+    if t is None or t.data_ptr() != g.data_ptr() or hit[2] != g._version or t._version != g._version \
+            or hit[3]._version != hit[4]:
         return None                        # (the last test: somebody scaled or clipped the noted sums in place)
-    return hit[3]
+    if hit[1] == tuple(g.shape) and g.is_contiguous():
+        return hit[3]
+    # the leading columns of a noted zero-padded buffer (alloc_padded): the same sums, cut to width
+    if g.dim() == 2 and len(hit[1]) == 2 and g.size(0) == hit[1][0] and g.size(1) < hit[1][1] and g.stride() == t.stride():
+        return hit[3][:g.size(1)]
+    return None
 
 
 def colsum(g: Tensor) -> Tensor:
