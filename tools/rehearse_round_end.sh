@@ -13,5 +13,5 @@ timeout -k 10 600 python bench.py > $R/bench.json 2> $R/bench.err || { tail -5 $
 python -c "
 import json; d=json.load(open('$R/bench.json')); r=d['roofline']
 print({k:d[k] for k in ('value','ms_per_step','epoch_ms','epoch_ms_fused','epoch_ms_fused_w1_update_in_backward')})
-print({k:r[k] for k in ('frac','frac_algorithmic','frac_traffic','frac_compulsory','l2_resident_ceiling_ms','launch_ms')})
+print({k:r.get(k) for k in ('frac','frac_basis','frac_algorithmic','frac_fabric','frac_hbm','frac_compulsory','l2_resident_ceiling_ms','launch_ms')})
 print(d['cpu_baseline']['value'], d['cpu_baseline']['csr']['value'])"
