@@ -245,16 +245,16 @@ def alloc_padded(n: int, F: int, device) -> Tensor:
     base[:, F:].zero_()
     view = base[:, :F]
     key = base.data_ptr()
-    _PADDED[key] = weakref.ref(base, lambda _, k=key: _PADDED.pop(k, None))
+    _PADDED[key] = (weakref.ref(base, lambda _, k=key: _PADDED.pop(k, None)), F)
     return view
 
 
 def padded_base(t: Tensor, width: int) -> Optional[Tensor]:
     """The zero-padded [n, width] buffer `t` is the leading part of, if it came from `alloc_padded` (else None)."""
     hit = _PADDED.get(t.data_ptr())
-    base = hit() if hit is not None else None
-    if base is None or t.dim() != 2 or base.shape != (t.size(0), width) or t.stride() != (width, 1) \
-            or base.data_ptr() != t.data_ptr() or t.dtype != torch.float32:
+    base = hit[0]() if hit is not None else None
+    if base is None or t.dim() != 2 or t.size(1) != hit[1] or base.shape != (t.size(0), width) \
+            or t.stride() != (width, 1) or base.data_ptr() != t.data_ptr() or t.dtype != torch.float32:
         return None
     return base
 

@@ -327,3 +327,25 @@ def test_committed_round3_bench_line_names_the_basis_of_its_roofline_fraction():
     assert "sweep" not in r["kernel"] and "k_spmm_gather" in r["kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["csr"]["value"] > c["value"] > 0
+
+
+def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():
+    """plan.alloc_padded / padded_base (odd layer widths): the [n, F] view is the leading part of a zero-padded
+    [n, F4] buffer; the buffer is given back for exactly that view and for nothing that merely looks like it."""
+    from pytextgcn_amd import plan
+    v = plan.alloc_padded(10, 7, "cpu")
+    assert v.shape == (10, 7) and v.stride() == (8, 1)
+    base = plan.padded_base(v, 8)
+    assert base is not None and base.shape == (10, 8) and base.data_ptr() == v.data_ptr()
+    assert float(base[:, 7].abs().sum()) == 0.0
+    v.fill_(3.0)                                             # writes through the view never touch the pad column
+    assert float(base[:, 7].abs().sum()) == 0.0 and float(base[:, :7].min()) == 3.0
+    assert plan.padded_base(v[1:], 8) is None                # another address
+    assert plan.padded_base(v[:, :6], 8) is None             # a narrower cut: column 6 is data, not padding
+    assert plan.padded_base(torch.zeros(10, 7), 8) is None   # somebody else's tensor
+    w = plan.alloc_padded(5, 8, "cpu")                       # a multiple of 4: a plain contiguous tensor
+    assert w.is_contiguous() and plan.padded_base(w, 8) is None
+    del base, v
+    import gc
+    gc.collect()
+    assert all(r[0]() is not None for r in plan._PADDED.values())   # dead buffers leave the registry
