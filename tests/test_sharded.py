@@ -92,3 +92,11 @@ def test_world4_graph_without_hub_structure_true_halo(monkeypatch):
     receiving rank's operator references instead of all-gathering the whole operand."""
     monkeypatch.setenv("TGCN_EXCHANGE", "halo")
     run(4, ["powerlaw_allhubs"])
+
+
+def test_world8_every_exchange_form(monkeypatch):
+    """The rank count of the target node (8 GPUs, BASELINE.json configs c4 / c5), over gloo with the oracle engine: the
+    hub partition with uneven shards and padding rows, all three exchange forms with one and three row chunks
+    (check_exchange_forms), and the model-level check under the halo form."""
+    monkeypatch.setenv("TGCN_EXCHANGE", "halo")
+    run(8, ["wordoc", "powerlaw_allhubs"])
