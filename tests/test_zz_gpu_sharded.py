@@ -49,10 +49,11 @@ def _n_gpus():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("exchange", ["collective", "p2p"])
+@pytest.mark.parametrize("exchange", ["collective", "p2p", "halo"])
 def test_two_rccl_ranks_one_per_gpu(cuda, monkeypatch, exchange):
-    """RCCL with more than one rank: all-gather / reduce-scatter / all-reduce (and the pairwise form)
-    over xGMI.  Needs two GPUs; the one-GPU test box skips it."""
+    """RCCL with more than one rank: all-gather / reduce-scatter / all-reduce, the pairwise form and the halo form
+    (all_to_all_single with split sizes) over xGMI -- and, inside the worker, every form against every other
+    (check_exchange_forms).  Needs two GPUs; the one-GPU test box skips it."""
     if _n_gpus() < 2:
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     monkeypatch.setenv("TGCN_EXCHANGE", exchange)
