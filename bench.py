@@ -441,10 +441,10 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10):
     direct = sg._stream_ordered(x)
 
     def halo_gather():
-        pack = x[:hp].index_select(0, d0.send_slots)
+        pack = sg._rows_gather(x[:hp], d0.send_slots)
         recv, work = sg._all_to_all_v(pack, d0.need_counts_l, d0.send_counts_l, direct)
         work.wait()
-        xbuf.index_copy_(0, d0.need_cols, recv)
+        sg._rows_scatter(xbuf, d0.need_cols, recv)
     out["halo_gather_referenced_rows_only"] = phase(halo_gather)
     out["rows_received_per_spmm"] = sg.exchange_rows()
     out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))

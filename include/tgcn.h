@@ -177,6 +177,21 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
                    double beta1, double beta2, double eps, double weight_decay, int64_t step,
                    const float *scalars_dev, void *workspace, size_t workspace_bytes, tgcn_stream stream);
 
+/* Row movement of the multi-GPU exchange (pytextgcn_amd/sharded.py; nothing in the reference corresponds: it is
+ * single-device, flat_amazon.py:84-86).  Row-major fp32 rows, int64 row indices on the device, enqueue only.
+ *   tgcn_rows_gather          out[i, :]    = x[idx[i], :]     (pack the hub rows a peer references)
+ *   tgcn_rows_scatter         y[idx[i], :] = x[i, :]          (place received rows in the gathered block; idx distinct)
+ *   tgcn_rows_reduce_ranked   y[row0 + j * row_step, :] += sum over q = 0 .. n_ranks-1, IN THAT ORDER, of
+ *                             recv[inv[q * n + j], :]  (inv < 0: rank q sent nothing for row j), j = 0 .. n-1:
+ *                             the reduce-scatter's local sum -- starting from zero, ranks in order, one add into y:
+ *                             the summation order all exchange forms share, so that they agree bit for bit. */
+int tgcn_rows_gather(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *out, int64_t ldo,
+                     tgcn_stream stream);
+int tgcn_rows_scatter(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *y, int64_t ldy,
+                      tgcn_stream stream);
+int tgcn_rows_reduce_ranked(const float *recv, int64_t ldr, const int32_t *inv, int n_ranks, int64_t n, int F,
+                            float *y, int64_t ldy, int64_t row0, int64_t row_step, tgcn_stream stream);
+
 /* tgcn_colsum -- replaces the autograd of `out += bias` (db = sum over rows of dOut).
  *   G [n_rows, F] fp32 stride ldg -> out [F]. */
 size_t tgcn_colsum_workspace_bytes(int64_t n_rows, int F);

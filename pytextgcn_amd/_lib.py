@@ -42,6 +42,10 @@ SIGNATURES = {
     "tgcn_spmm_adam": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "tgcn_rows_gather": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "tgcn_rows_scatter": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "tgcn_rows_reduce_ranked": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_int64,
+                                        c_int64, c_void_p]),
     "tgcn_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "tgcn_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),

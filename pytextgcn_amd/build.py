@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtgcn.so")
-SOURCES = ["spmm.hip", "colsum.hip", "train.hip", "dense.hip", "plan.hip", "graphbuilder.hip", "error.cpp"]
+SOURCES = ["spmm.hip", "colsum.hip", "rows.hip", "train.hip", "dense.hip", "plan.hip", "graphbuilder.hip", "error.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(_ROOT, "include", "tgcn.h")]
 
 

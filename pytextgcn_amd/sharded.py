@@ -90,6 +90,31 @@ class HipEngine:
         from .functional import masked_cross_entropy
         return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
 
+    # row movement of the exchange (libtgcn.so `tgcn_rows_*`, csrc/rows.hip)
+    def rows_gather(self, x: Tensor, idx: Tensor) -> Tensor:
+        """x[idx] (rows), packed for sending."""
+        from . import _lib
+        from .plan import _stream_ptr
+        out = torch.empty(idx.numel(), x.size(1), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().tgcn_rows_gather(x.data_ptr(), x.stride(0), idx.data_ptr(), idx.numel(), x.size(1),
+                                                out.data_ptr(), out.stride(0), _stream_ptr(x.device)))
+        return out
+
+    def rows_scatter_(self, y: Tensor, idx: Tensor, x: Tensor) -> None:
+        """y[idx] = x (rows; idx distinct)."""
+        from . import _lib
+        from .plan import _stream_ptr
+        _lib.check(_lib.load().tgcn_rows_scatter(x.data_ptr(), x.stride(0), idx.data_ptr(), idx.numel(), x.size(1),
+                                                 y.data_ptr(), y.stride(0), _stream_ptr(y.device)))
+
+    def reduce_ranked_(self, y: Tensor, recv: Tensor, inv: Tensor, n_ranks: int, n: int, row0: int, step: int) -> None:
+        """y[row0 + j * step] += sum over ranks q, in order, of recv[inv[q, j]] (inv < 0: nothing from q), j < n."""
+        from . import _lib
+        from .plan import _stream_ptr
+        _lib.check(_lib.load().tgcn_rows_reduce_ranked(
+            recv.data_ptr() if recv.numel() else None, recv.stride(0) if recv.numel() else y.size(1), inv.data_ptr(),
+            n_ranks, n, y.size(1), y.data_ptr(), y.stride(0), row0, step, _stream_ptr(y.device)))
+
 
 class _Done:
     """A finished transfer (the staged exchanges complete before they return)."""
@@ -190,11 +215,12 @@ class Partition:
 
 class _Chunk:
     """One row chunk of A_r (hub slots s with s % K == k) and the lists of its pruned reduce-scatter."""
-    __slots__ = ("op", "k", "ck", "n_own", "touch_rows", "touch_counts", "recv_counts", "recv_pos")
+    __slots__ = ("op", "k", "ck", "n_own", "touch_rows", "touch_counts", "recv_counts", "recv_pos", "inv_halo", "inv_dense")
 
     def __init__(self, op, k, ck, n_own):
         self.op, self.k, self.ck, self.n_own = op, k, ck, n_own
         self.touch_rows = self.touch_counts = self.recv_counts = self.recv_pos = None
+        self.inv_halo = self.inv_dense = None      # [W, n_own] int32: row of the receive buffer rank q's partial of row j sits in
 
 
 class _Direction:
@@ -426,6 +452,14 @@ class ShardedGraph:
                 ch.touch_counts = [int(v) for v in counts.tolist()]
                 ch.recv_counts = [int(v) for v in got_counts.tolist()]
                 ch.recv_pos = got                          # positions inside the chunk's own rows, rank order
+                # the same lists as tables for the one-pass reduction kernel (tgcn_rows_reduce_ranked)
+                n_own = ch.n_own
+                inv = torch.full((W, max(n_own, 1)), -1, dtype=torch.int32, device=self.device)
+                src = torch.repeat_interleave(torch.arange(W, device=self.device), got_counts.to(self.device))
+                inv[src, got] = torch.arange(got.numel(), dtype=torch.int32, device=self.device)
+                ch.inv_halo = inv[:, :n_own].contiguous()
+                ar = torch.arange(n_own, dtype=torch.int32, device=self.device)
+                ch.inv_dense = (torch.arange(W, dtype=torch.int32, device=self.device).unsqueeze(1) * ch.ck + ar).contiguous()
         self.rs_chunks = K
 
     # ---- data movement ---------------------------------------------------------------------------
@@ -512,13 +546,24 @@ class ShardedGraph:
             return xbuf, lambda: [w.wait() for w in works]
         # halo: only the rows somebody reads travel
         xbuf = self._gather_buffer(x_local, True)
-        pack = shard.index_select(0, d.send_slots)
+        pack = self._rows_gather(shard, d.send_slots)
         recv, work = self._all_to_all_v(pack, d.need_counts_l, d.send_counts_l, direct)
 
         def finish():
             work.wait()
-            xbuf.index_copy_(0, d.need_cols, recv)
+            self._rows_scatter(xbuf, d.need_cols, recv)
         return xbuf, finish
+
+    def _rows_gather(self, x: Tensor, idx: Tensor) -> Tensor:
+        f = getattr(self.engine, "rows_gather", None)
+        return f(x, idx) if (f is not None and x.is_cuda) else x.index_select(0, idx)
+
+    def _rows_scatter(self, y: Tensor, idx: Tensor, x: Tensor) -> None:
+        f = getattr(self.engine, "rows_scatter_", None)
+        if f is not None and y.is_cuda:
+            f(y, idx, x)
+        else:
+            y.index_copy_(0, idx, x)
 
     def _all_to_all_v(self, src: Tensor, out_sizes, in_sizes, direct: bool):
         """all_to_all_single with split sizes (rows); device tensors over a host-serviced backend go through pinned
@@ -555,23 +600,30 @@ class ShardedGraph:
                 work.wait()
                 add_to(y_hub, out)
             return finish
+        ranked = getattr(self.engine, "reduce_ranked_", None) if partial.is_cuda else None
         if self.exchange == "p2p":
             sizes = [ck] * W
             recv, work = self._all_to_all_v(partial, sizes, sizes, direct)
 
             def finish(y_hub):
                 work.wait()
-                acc = recv[:ck].clone()                     # the ranks' partial rows, added in rank order
-                for q in range(1, W):
+                if ranked is not None:                      # one pass: zero + the ranks' rows in rank order, then += into y
+                    ranked(y_hub, recv, ch.inv_dense, W, ch.n_own, ch.k, K)
+                    return
+                acc = torch.zeros(ck, F, dtype=partial.dtype, device=partial.device)
+                for q in range(W):                          # the ranks' partial rows, added in rank order
                     acc += recv[q * ck:(q + 1) * ck]
                 add_to(y_hub, acc)
             return finish
         # halo: only rows with entries travel; absent rows are exact zeros in the other forms
-        pack = partial.index_select(0, ch.touch_rows)
+        pack = self._rows_gather(partial, ch.touch_rows)
         recv, work = self._all_to_all_v(pack, ch.recv_counts, ch.touch_counts, direct)
 
         def finish(y_hub):
             work.wait()
+            if ranked is not None:
+                ranked(y_hub, recv, ch.inv_halo, W, ch.n_own, ch.k, K)
+                return
             acc = torch.zeros(ck, F, dtype=partial.dtype, device=partial.device)
             off = 0
             for q in range(W):                              # rank order; a rank's rows are distinct

@@ -446,6 +446,48 @@ def test_error_behaviour(cuda):
     assert torch.equal(cs, torch.zeros(5, device=cuda))                      # no rows: the sums are zero, not stale
 
 
+@pytest.mark.parametrize("F", [200, 64, 7, 260])
+def test_row_movement_kernels_of_the_exchange(cuda, F):
+    """tgcn_rows_gather / _scatter / _reduce_ranked (csrc/rows.hip) against torch's index ops; the ranked reduction
+    against the sum it documents -- zero, plus the ranks' rows in rank order, then one add into y -- bit for bit."""
+    from pytextgcn_amd.sharded import HipEngine
+    eng = HipEngine()
+    gen = torch.Generator().manual_seed(F)
+    x = torch.randn(5000, F, generator=gen).to(cuda)
+    idx = torch.randperm(5000, generator=gen)[:1777].to(cuda)
+    assert torch.equal(eng.rows_gather(x, idx), x.index_select(0, idx))
+    wide = torch.randn(5000, F + 8, generator=gen).to(cuda)               # strided source
+    assert torch.equal(eng.rows_gather(wide[:, 4:4 + F], idx), wide[:, 4:4 + F].index_select(0, idx))
+    y = torch.zeros(6000, F, device=cuda)
+    rows = torch.randn(1777, F, generator=gen).to(cuda)
+    eng.rows_scatter_(y, idx, rows)
+    ref = torch.zeros(6000, F, device=cuda).index_copy_(0, idx, rows)
+    assert torch.equal(y, ref)
+    assert eng.rows_gather(x, idx[:0]).shape == (0, F)
+    # ranked reduction: W ranks, n rows, some rows missing from some ranks; target rows k, k + K, ...
+    W, n, K, k = 5, 900, 3, 1
+    inv = torch.full((W, n), -1, dtype=torch.int32)
+    recv_rows = []
+    for q in range(W):
+        have = torch.rand(n, generator=gen) < 0.7
+        pos = have.nonzero().flatten()
+        inv[q, pos] = torch.arange(len(recv_rows), len(recv_rows) + pos.numel(), dtype=torch.int32)
+        recv_rows += [None] * pos.numel()
+    recv = torch.randn(len(recv_rows), F, generator=gen).to(cuda)
+    yh = torch.randn(n * K + 5, F, generator=gen).to(cuda)
+    want = yh.clone()
+    acc = torch.zeros(n, F, device=cuda)
+    for q in range(W):
+        sel = (inv[q] >= 0).to(cuda)
+        acc[sel] += recv[inv[q][inv[q] >= 0].long().to(cuda)]
+    want[k:k + K * n:K] += acc
+    eng.reduce_ranked_(yh, recv, inv.to(cuda), W, n, k, K)
+    assert torch.equal(yh, want)
+    lib = _lib.load()
+    assert lib.tgcn_rows_gather(x.data_ptr(), F - 1, idx.data_ptr(), 3, F, y.data_ptr(), F, None) == _lib.E_INVALID
+    assert lib.tgcn_rows_reduce_ranked(None, F, inv.to(cuda).data_ptr(), 0, n, F, yh.data_ptr(), F, 0, 1, None) == _lib.E_INVALID
+
+
 def test_synthetic_graphs_do_not_depend_on_the_device_they_are_built_on(cuda):
     """pytextgcn_amd.synth draws every random number from a CPU generator: the graph built on the GPU (what bench.py
     and the large parity cases use) is bit for bit the graph a CPU-only host builds from the same seed."""
