@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Per-rank COMPUTE of the row-partitioned SpMM at world sizes 2/4/8, measured on one GPU: builds the
-local operators A_r, B_r of pytextgcn_amd.sharded for a few ranks of the c4 graph (no process group, no
-collectives) and times them.  Gives the compute side of the N-GPU step; the exchange (all-gather +
-reduce-scatter of the V x F hub block) comes on top and can only be measured on a multi-GPU node."""
+"""Per-rank COMPUTE of the row-partitioned SpMM at world sizes 2/4/8, measured on ONE GPU: builds the local operators
+A_r, B_r of pytextgcn_amd.sharded for one rank of the c4 graph (no process group, no collectives) and times them --
+A_r whole and as 4 row chunks (TGCN_RS_CHUNKS), B_r at the hidden width (split operand) and at the class width (one
+buffer).  Gives the compute side of the N-GPU step; the exchange comes on top and can only be measured on a multi-GPU
+node.   python tools/sim_shard_compute.py [world ...]"""
 import json
 import os
 import sys
@@ -15,11 +16,11 @@ from pytextgcn_amd import synth  # noqa: E402
 from pytextgcn_amd.sharded import HipEngine, Partition, ShardedGraph  # noqa: E402
 
 dev = torch.device("cuda:0")
-N, E, F = 2_000_000, 50_000_000, 200
+N, E = 2_000_000, 50_000_000
 g = synth.word_doc_graph(N, E, seed=44, device=dev, features="none")
 hubs = torch.arange(N, device=dev) < g.n_vocab
 eng = HipEngine()
-row, col, val, sym = eng.normalized_triplets(g.edge_index, g.edge_attr, N, True, True, False)
+dis, loop_w = eng.gcn_norm(g.edge_index, g.edge_attr, N, 1)
 
 
 def timed(fn, reps=10):
@@ -35,19 +36,42 @@ def timed(fn, reps=10):
     return ev[0].elapsed_time(ev[1]) / reps
 
 
-for world in (2, 4, 8):
+for world in ([int(w) for w in sys.argv[1:]] or [2, 4, 8]):
     part = Partition(g.edge_index, N, world, hubs)
-    for rank in sorted({0, world - 1}):
-        sg = ShardedGraph.__new__(ShardedGraph)
-        sg.world, sg.rank, sg.engine, sg.part = world, rank, eng, part
-        sg.hp, sg.rp, sg.n_local = part.hp, part.rp, part.n_local
-        A, B = sg._local_ops(row, col, val)
+    rank = 0
+    sg = ShardedGraph.__new__(ShardedGraph)          # the construction steps that need no process group
+    sg.world, sg.rank, sg.engine, sg.part, sg.device = world, rank, eng, part, dev
+    sg.hp, sg.rp, sg.n_local = part.hp, part.rp, part.n_local
+    sg.owned = part.owned(rank)
+    sg.real = sg.owned >= 0
+    sg._dis, sg._loop_w, sg._loops = dis, loop_w, 1
+    d = sg._local_ops(g.edge_index, g.edge_attr, transpose=False)
+    A, B = d.A, d.B
+    hp, rp, W = sg.hp, sg.rp, world
+    rec = {"world": world, "hub_rows_per_rank": hp, "regular_rows": rp, "A_nnz": A.nnz, "B_nnz": B.nnz,
+           "A_hot": A.stats()["hot_rows"], "B_hot": B.stats()["hot_rows"]}
+    # A_r as K = 4 row chunks (hub slot s -> chunk s % 4), as ShardedGraph.set_rs_chunks cuts them
+    K = 4
+    row, col, w = d.A_entries
+    owner, slot = row // hp, row % hp
+    ck = (hp + K - 1) // K
+    chunks = []
+    for k in range(K):
+        sel = (slot % K) == k
+        chunks.append(eng.make_op(owner[sel] * ck + slot[sel] // K, col[sel], w[sel], W * ck, rp))
+    rec["A_chunk_hot_rows"] = [c.stats()["hot_rows"] for c in chunks]
+    for F in (200, 64):
         x_local = torch.randn(sg.n_local, F, device=dev)
-        xbuf = torch.randn(world * sg.hp, F, device=dev)
-        tA = timed(lambda: A.spmm(x_local[sg.hp:]))
-        tB = timed(lambda: B.spmm(xbuf, None, x2=x_local[sg.hp:]))
-        print(json.dumps({"world": world, "rank": rank, "hub_rows_per_rank": sg.hp, "regular_rows": sg.rp,
-                          "A_nnz": A.nnz, "B_nnz": B.nnz, "A_hot": A.stats()["hot_rows"], "B_hot": B.stats()["hot_rows"],
-                          "A_ms": round(tA, 3), "B_ms": round(tB, 3), "compute_ms": round(tA + tB, 3),
-                          "exchange_MB_each_way": round(2 * (world - 1) * sg.hp * F * 4 / 1e6, 1)}), flush=True)
-        A.close(); B.close()
+        xbuf = torch.randn(W * hp + rp, F, device=dev)
+        xbuf[W * hp:] = x_local[hp:]
+        rec[f"A_ms_F{F}"] = round(timed(lambda: A.spmm(x_local[hp:])), 3)
+        rec[f"A_4chunks_ms_F{F}"] = round(timed(lambda: [c.spmm(x_local[hp:]) for c in chunks]), 3)
+        if F > 128:
+            rec[f"B_ms_F{F}"] = round(timed(lambda: B.spmm(xbuf[:W * hp], None, x2=x_local[hp:])), 3)
+        else:
+            rec[f"B_ms_F{F}"] = round(timed(lambda: B.spmm(xbuf, None)), 3)
+            rec[f"B_split_operand_ms_F{F}"] = round(timed(lambda: B.spmm(xbuf[:W * hp], None, x2=x_local[hp:])), 3)
+        rec[f"exchange_MB_each_way_F{F}"] = round((W - 1) * hp * F * 4 / 1e6, 1)
+    print(json.dumps(rec), flush=True)
+    for op in [A, B] + chunks:
+        op.close()
