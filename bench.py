@@ -589,7 +589,7 @@ def main():
     exchange_selection = None
     if world > 1 and "TGCN_EXCHANGE" not in os.environ:
         forms = list(sg.EXCHANGES)
-        chunkings = [1, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
+        chunkings = [1, 2, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
         trial = {}
         for K in chunkings:
             sg.set_rs_chunks(K)
