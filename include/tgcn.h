@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 2
+#define TGCN_ABI_VERSION 3
 
 enum {
     TGCN_OK = 0,
@@ -65,12 +65,23 @@ const char *tgcn_last_error(void);
  *   add_self_loops        GCNConv(add_self_loops=...) -- the reference always passes True; the value
  *                         is also the weight of an added loop: 1 -> 1.0, 2 -> 2.0 (improved=True)
  *   normalize             GCNConv(normalize=...)      -- the reference keeps the default True; as in
- *                         PyG, loops are added inside gcn_norm, i.e. only when normalize != 0
+ *                         PyG, loops are added inside gcn_norm, i.e. only when normalize != 0.  The value also
+ *                         selects how a node's degree is summed (enum below):
+ *                           TGCN_NORM_ACCURATE (1)   float64 sum, rounded to fp32 once (the default of the Python layer);
+ *                                                    w_hat = w * (d^-1/2[src] * d^-1/2[dst]): a symmetric graph stays
+ *                                                    BITWISE symmetric and M^T is not stored;
+ *                           TGCN_NORM_REFERENCE (2)  the bits of the reference's CPU path: ONE fp32 accumulator per node,
+ *                                                    weights added sequentially in edge order, the self loop last (PyG
+ *                                                    scatter_add on the CPU after add_remaining_self_loops), and PyG's
+ *                                                    association (d^-1/2[src] * w) * d^-1/2[dst] -- on hub nodes with
+ *                                                    ~10^6 edges this differs from the accurate sum by a few 1e-5 relative.
  *   row_begin, row_end    rows [row_begin,row_end) of M and of M^T that this plan will produce
  *                         (1-D row partition across GPUs); 0, n_nodes for the whole graph.  The
  *                         normalisation is always computed over the WHOLE edge list.
  *   device                HIP device ordinal that owns every pointer
  */
+enum { TGCN_NORM_OFF = 0, TGCN_NORM_ACCURATE = 1, TGCN_NORM_REFERENCE = 2 };   /* `normalize` of tgcn_plan_create */
+enum { TGCN_DEGREE_ACCURATE = 0, TGCN_DEGREE_REFERENCE = 1 };                  /* `degree_sum` of tgcn_gcn_norm    */
 int tgcn_plan_create(int64_t n_nodes, int64_t n_edges,
                      const int64_t *src, int64_t src_stride,
                      const int64_t *dst, int64_t dst_stride,
@@ -91,7 +102,9 @@ int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
  * reference runs it, models.py:11-20): for every node dis[n] = deg[n]^-1/2 (inf -> 0) with deg the weighted
  * in-degree at the target incl. the self loop, and loop_w[n] = the weight of that loop (the last input loop's,
  * else add_self_loops as 1.0 / 2.0; all zeros when add_self_loops = 0).  The normalised weight of edge e is
- * then w[e] * (dis[src] * dis[dst]), the association tgcn_plan_create uses.  No counterpart in the single-
+ * then w[e] * (dis[src] * dis[dst]) -- (dis[src] * w[e]) * dis[dst] in the reference-order mode -- the association
+ * tgcn_plan_create uses.  It IS the routine tgcn_plan_create runs (degree_sum = TGCN_DEGREE_ACCURATE / _REFERENCE as
+ * its normalize = TGCN_NORM_ACCURATE / _REFERENCE): same chunking, same sums, same bits.  No counterpart in the single-
  * device reference: the 1-D partition (pytextgcn_amd/sharded.py) calls it so that every rank can cut its own
  * local operators out of the edge list WITHOUT building the whole-graph plan -- the edge list is walked in
  * chunks (TGCN_NORM_CHUNK edges, default 2^25), scratch is O(chunk) + O(n_nodes); deterministic.
@@ -100,7 +113,7 @@ int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
 int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges,
                   const int64_t *src, int64_t src_stride,
                   const int64_t *dst, int64_t dst_stride,
-                  const float *w, int add_self_loops, float *dis, float *loop_w,
+                  const float *w, int add_self_loops, int degree_sum, float *dis, float *loop_w,
                   int device, tgcn_stream stream);
 
 int tgcn_plan_destroy(tgcn_plan *plan);
@@ -184,13 +197,17 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
  *   tgcn_rows_reduce_ranked   y[row0 + j * row_step, :] += sum over q = 0 .. n_ranks-1, IN THAT ORDER, of
  *                             recv[inv[q * n + j], :]  (inv < 0: rank q sent nothing for row j), j = 0 .. n-1:
  *                             the reduce-scatter's local sum -- starting from zero, ranks in order, one add into y:
- *                             the summation order all exchange forms share, so that they agree bit for bit. */
-int tgcn_rows_gather(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *out, int64_t ldo,
-                     tgcn_stream stream);
+ *                             the summation order all exchange forms share, so that they agree bit for bit.
+ * n_x_rows / n_y_rows / n_recv_rows are the row counts of the INDEXED buffers: an index outside them is skipped on the
+ * device (the calls only enqueue and cannot report it), so a bad list can never read or write outside a buffer;
+ * tgcn_rows_reduce_ranked returns TGCN_E_RANGE when row0 + (n - 1) * row_step >= n_y_rows. */
+int tgcn_rows_gather(const float *x, int64_t ldx, int64_t n_x_rows, const int64_t *idx, int64_t n, int F, float *out,
+                     int64_t ldo, tgcn_stream stream);
 int tgcn_rows_scatter(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *y, int64_t ldy,
-                      tgcn_stream stream);
-int tgcn_rows_reduce_ranked(const float *recv, int64_t ldr, const int32_t *inv, int n_ranks, int64_t n, int F,
-                            float *y, int64_t ldy, int64_t row0, int64_t row_step, tgcn_stream stream);
+                      int64_t n_y_rows, tgcn_stream stream);
+int tgcn_rows_reduce_ranked(const float *recv, int64_t ldr, int64_t n_recv_rows, const int32_t *inv, int n_ranks,
+                            int64_t n, int F, float *y, int64_t ldy, int64_t n_y_rows, int64_t row0, int64_t row_step,
+                            tgcn_stream stream);
 
 /* tgcn_colsum -- replaces the autograd of `out += bias` (db = sum over rows of dOut).
  *   G [n_rows, F] fp32 stride ldg -> out [F]. */

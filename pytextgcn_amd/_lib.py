@@ -12,9 +12,12 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
+NORM_OFF, NORM_ACCURATE, NORM_REFERENCE = 0, 1, 2          # `normalize` of tgcn_plan_create
+DEGREE_ACCURATE, DEGREE_REFERENCE = 0, 1                   # `degree_sum` of tgcn_gcn_norm
+DEGREE_SUMS = {"accurate": DEGREE_ACCURATE, "reference": DEGREE_REFERENCE}
 
 (Q_N_NODES, Q_N_ROWS, Q_NNZ, Q_NNZ_T, Q_SYMMETRIC, Q_ITEMS, Q_ITEMS_T, Q_LONG_ROWS, Q_LONG_ROWS_T,
  Q_SEGMENTS, Q_SEGMENTS_T, Q_DEVICE_BYTES, Q_ROW_BEGIN, Q_HAS_TRANSPOSE, Q_N_ROWS_T, Q_HOT_ROWS,
@@ -29,7 +32,7 @@ SIGNATURES = {
                                  POINTER(c_void_p)]),
     "tgcn_plan_create_coo": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_void_p, POINTER(c_void_p)]),
-    "tgcn_gcn_norm": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+    "tgcn_gcn_norm": (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p,
                               c_void_p, c_int, c_void_p]),
     "tgcn_plan_destroy": (c_int, [c_void_p]),
     "tgcn_plan_query": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
@@ -42,10 +45,10 @@ SIGNATURES = {
     "tgcn_spmm_adam": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
-    "tgcn_rows_gather": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
-    "tgcn_rows_scatter": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
-    "tgcn_rows_reduce_ranked": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_int64,
-                                        c_int64, c_void_p]),
+    "tgcn_rows_gather": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "tgcn_rows_scatter": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),
+    "tgcn_rows_reduce_ranked": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64,
+                                        c_int64, c_int64, c_int64, c_void_p]),
     "tgcn_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "tgcn_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),

@@ -222,8 +222,11 @@ def glorot_(t: Tensor) -> Tensor:
 class GCNConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, improved: bool = False,
                  cached: bool = False, add_self_loops: bool = True, normalize: bool = True,
-                 bias: bool = True, **kwargs):
+                 bias: bool = True, degree_sum: Optional[str] = None, **kwargs):
+        """`degree_sum` (not a PyG argument): "accurate" | "reference" -- how gcn_norm's degrees are summed
+        (pytextgcn_amd.plan); None = the package default, `pytextgcn_amd.set_degree_sum`."""
         super().__init__()
+        self.degree_sum = degree_sum
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.improved = improved
@@ -268,7 +271,7 @@ class GCNConv(nn.Module):
 
     def plan(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> GraphPlan:
         loops = (2 if self.improved else 1) if self.add_self_loops else 0     # fill weight of added loops
-        return plan_for(edge_index, edge_weight, x.size(0), loops, self.normalize)
+        return plan_for(edge_index, edge_weight, x.size(0), loops, self.normalize, getattr(self, "degree_sum", None))
 
     def features_times(self, x: Tensor, w: Tensor) -> Tensor:
         """X @ w for the feature formats of text2graph.py:226-246 (`w` has `in_channels` rows)."""

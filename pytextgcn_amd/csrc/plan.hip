@@ -108,25 +108,100 @@ __global__ void k_make_keys(int64_t E, const int64_t *__restrict__ src, int64_t 
     }
 }
 
-// ---- tgcn_gcn_norm: the degree factors on their own, over the edge list in bounded chunks ------------
-// keys of one chunk of edges [lo, lo + n): dst << 32 | src, dropped entries (input self-loops when loops are
-// re-appended, out-of-range indices) get the key N << 32 and sort behind every real row
-__global__ void k_norm_keys(int64_t lo, int64_t n, const int64_t *__restrict__ src, int64_t ss,
-                            const int64_t *__restrict__ dst, int64_t ds, const float *__restrict__ w, int64_t N,
-                            int add_loops, uint64_t *__restrict__ keys, float *__restrict__ vals) {
+// ---- degree factors of gcn_norm: ONE routine (degree_factors, below) behind tgcn_plan_create and tgcn_gcn_norm -------
+// The edge list is walked in bounded chunks; a chunk is sorted by TARGET only (32-bit keys, stable: the entries of a
+// row keep their edge order) and every row's entries are summed by one wavefront, in one of two ways:
+//   accurate   float64 partial sums per lane, folded in a fixed order, accumulated in float64 over the chunks and
+//              rounded to fp32 ONCE together with the loop weight: the correctly rounded degree for all practical purposes;
+//   reference  what PyG-1.6.3 gcn_norm does on the CPU (the reference's path, textgcn/lib/models.py:11-20 ->
+//              scatter_add(edge_weight, col)): ONE fp32 accumulator per node, the weights added sequentially in edge
+//              order, the node's self loop last (add_remaining_self_loops moves the loops to the tail).  A hub node's
+//              ~10^6 terms then carry the rounding of a sequential fp32 sum -- this mode reproduces those bits.
+// keys of the chunk of edges [lo, lo + n): the target; dropped entries (input self-loops when loops are re-appended,
+// out-of-range indices) get the key N and sort behind every real row
+__global__ void k_deg_keys(int64_t lo, int64_t n, const int64_t *__restrict__ src, int64_t ss,
+                           const int64_t *__restrict__ dst, int64_t ds, const float *__restrict__ w, int64_t n_rows,
+                           int64_t n_cols, int add_loops, uint32_t *__restrict__ keys, float *__restrict__ vals) {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    const uint64_t drop = static_cast<uint64_t>(N) << 32;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t s = src[(lo + i) * ss], d = dst[(lo + i) * ds];
-        const bool bad = s < 0 || s >= N || d < 0 || d >= N;
-        keys[i] = (bad || (add_loops && s == d)) ? drop : (static_cast<uint64_t>(d) << 32) | static_cast<uint64_t>(s);
+        const bool bad = s < 0 || s >= n_cols || d < 0 || d >= n_rows;
+        keys[i] = (bad || (add_loops && s == d)) ? static_cast<uint32_t>(n_rows) : static_cast<uint32_t>(d);
         vals[i] = w ? w[lo + i] : 1.0f;
     }
 }
 
-// loop weight of every node (the last input loop's weight, else `fill`) and the start of its degree sum
-__global__ void k_norm_loops(int64_t N, int add_loops, float fill, const unsigned long long *__restrict__ loop_eid,
-                             const float *__restrict__ w, float *__restrict__ loop_w, double *__restrict__ deg) {
+// rowptr[r] = first position of the sorted chunk whose key is >= r
+__global__ void k_deg_rowptr(const uint32_t *__restrict__ keys, int64_t n, int64_t N, int32_t *__restrict__ rowptr) {
+    const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r > N) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < static_cast<uint32_t>(r))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rowptr[r] = static_cast<int32_t>(lo);
+}
+
+// accurate: one wavefront per row of a sorted chunk, float64 sums in a fixed lane order, added to the row's float64
+__global__ void k_deg_sum_f64(const int32_t *__restrict__ rowptr, const float *__restrict__ vals, int64_t N,
+                              double *__restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
+    // grid-stride over the rows: the launch grid is capped, N is not -- config c5 has 8 M rows
+    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (b == e) continue;
+        // four independent chains per lane: the hottest word row of c4 has ~10^6 entries
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int32_t j = b + lane;
+        for (; j + 3 * 64 < e; j += 4 * 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += static_cast<double>(vals[j + u * 64]);
+        }
+        for (; j < e; j += 64) acc[0] += static_cast<double>(vals[j]);
+        double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) deg[r] += s;
+    }
+}
+
+// reference: one wavefront per row, but ONE fp32 accumulator: the lanes fetch 64 weights at a time (coalesced) and the
+// wave adds them one after the other in edge order, continuing the sum the earlier chunks left in deg[r]
+__global__ void k_deg_sum_seq(const int32_t *__restrict__ rowptr, const float *__restrict__ vals, int64_t N,
+                              float *__restrict__ deg) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
+    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (b == e) continue;
+        float s = deg[r];
+        float next = b + lane < e ? vals[b + lane] : 0.f;
+        for (int32_t j = b; j < e; j += 64) {
+            const float v = next;
+            if (j + 64 < e) next = j + 64 + lane < e ? vals[j + 64 + lane] : 0.f;      // prefetch under the chain
+            const int cnt = min(64, e - j);
+            if (cnt == 64) {
+#pragma unroll
+                for (int i = 0; i < 64; ++i) s += __shfl(v, i, 64);
+            } else {
+                for (int i = 0; i < cnt; ++i) s += __shfl(v, i, 64);
+            }
+        }
+        if (lane == 0) deg[r] = s;
+    }
+}
+
+// loop weight of every node (the last input loop's weight, else `fill`), added to the degree LAST; dis = deg^-1/2
+__global__ void k_deg_finish(int64_t N, int reference, const double *__restrict__ deg64, const float *__restrict__ deg32,
+                             int add_loops, float fill, const unsigned long long *__restrict__ loop_eid,
+                             const float *__restrict__ w, float *__restrict__ dis, float *__restrict__ loop_w) {
+#pragma clang fp contract(off)
     const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float lw = 0.f;
@@ -135,36 +210,9 @@ __global__ void k_norm_loops(int64_t N, int add_loops, float fill, const unsigne
         lw = le ? (w ? w[le - 1] : 1.0f) : fill;
     }
     if (loop_w) loop_w[n] = lw;
-    deg[n] = static_cast<double>(lw);
-}
-
-// one wavefront per row of a sorted chunk: fp32 sum in a fixed lane order, added to the row's double
-__global__ void k_norm_deg(const int32_t *__restrict__ rowptr, const float *__restrict__ vals, int64_t N,
-                           double *__restrict__ deg) {
-    const int lane = threadIdx.x & 63;
-    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
-    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
-        const int32_t b = rowptr[r], e = rowptr[r + 1];
-        if (b == e) continue;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int32_t j = b + lane;
-        for (; j + 7 * 64 < e; j += 8 * 64) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += vals[j + u * 64];
-        }
-        for (; j < e; j += 64) acc[0] += vals[j];
-        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) deg[r] += static_cast<double>(s);
-    }
-}
-
-__global__ void k_norm_dis(int64_t N, const double *__restrict__ deg, float *__restrict__ dis) {
-    const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float d = 1.0f / sqrtf(static_cast<float>(deg[n]));   // deg.pow(-0.5) on the fp32 degree
-    if (isinf(d)) d = 0.0f;                               // masked_fill_(== inf, 0)
+    const float deg = reference ? deg32[n] + lw : static_cast<float>(deg64[n] + static_cast<double>(lw));
+    float d = 1.0f / sqrtf(deg);          // deg.pow(-0.5): torch evaluates it as 1 / sqrt, both correctly rounded
+    if (isinf(d)) d = 0.0f;               // masked_fill_(== inf, 0)
     dis[n] = d;
 }
 
@@ -185,38 +233,12 @@ __global__ void k_rowptr(const uint64_t *__restrict__ keys, int64_t nnz, int64_t
     rowptr[r] = static_cast<int32_t>(lo);
 }
 
-// One wavefront per row: weighted in-degree (loop included), then deg^-1/2 with inf -> 0.
-__global__ void k_deg_inv_sqrt(const int32_t *__restrict__ rowptr, const float *__restrict__ vals,
-                               int64_t N, float *__restrict__ dis) {
-    const int lane = threadIdx.x & 63;
-    const int64_t waves = int64_t(gridDim.x) * (blockDim.x >> 6);
-    // grid-stride over the rows: the launch grid is capped (grid_for), N is not -- config c5 has 8 M rows
-    for (int64_t r = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); r < N; r += waves) {
-        const int32_t b = rowptr[r], e = rowptr[r + 1];
-        // eight independent partial sums per lane: the hottest word row of c4 has ~10^6 entries and a
-        // single dependent chain per lane made this kernel latency-bound (7.3 ms -> see profiles/)
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int32_t j = b + lane;
-        for (; j + 7 * 64 < e; j += 8 * 64) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += vals[j + u * 64];
-        }
-        for (; j < e; j += 64) acc[0] += vals[j];
-        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) {
-            float d = 1.0f / sqrtf(s);  // deg.pow(-0.5)
-            if (isinf(d)) d = 0.0f;     // masked_fill_(== inf, 0)
-            dis[r] = d;
-        }
-    }
-}
-
 // w_hat = w * (dis[src] * dis[dst]).  PyG evaluates dis[src] * w * dis[dst] left to right, which
 // rounds (i,j) and (j,i) differently; pairing the two degree factors first keeps a symmetric graph
-// bitwise symmetric (so M^T need not be stored) at <= 1 ulp from PyG's value.  Emits the CSR pair
-// array of M and the (src << 32 | dst, w_hat) pairs that are sorted next to give M^T.
+// bitwise symmetric (so M^T need not be stored) at <= 1 ulp from PyG's value.  normalize == 2 (the
+// reference-order mode) keeps PyG's association, (dis[src] * w) * dis[dst]: the reference's bits, and M^T is
+// then stored next to M.  Emits the CSR pair array of M and the (src << 32 | dst, w_hat) pairs that are
+// sorted next to give M^T.
 __global__ void k_finalize(const uint64_t *__restrict__ keys, const float *__restrict__ vals,
                            int64_t nnz, const float *__restrict__ dis, int normalize,
                            int2 *__restrict__ cv, uint64_t *__restrict__ keys_t,
@@ -226,7 +248,10 @@ __global__ void k_finalize(const uint64_t *__restrict__ keys, const float *__res
         const uint64_t k = keys[j];
         const uint32_t d = static_cast<uint32_t>(k >> 32), s = static_cast<uint32_t>(k);
         float v = vals[j];
-        if (normalize) v = v * (dis[s] * dis[d]);
+        if (normalize == 2)
+            v = (dis[s] * v) * dis[d];
+        else if (normalize)
+            v = v * (dis[s] * dis[d]);
         cv[j] = make_int2(static_cast<int>(s), __float_as_int(v));
         keys_t[j] = (static_cast<uint64_t>(s) << 32) | d;
         vals_t[j] = v;
@@ -260,7 +285,8 @@ __global__ void k_slice_rowptr(const int32_t *__restrict__ rowptr, int64_t row_b
     if (i <= n_rows) out[i] = rowptr[row_begin + i] - rowptr[row_begin];
 }
 
-int sort_pairs(uint64_t *keys_in, uint64_t *keys_out, float *vals_in, float *vals_out, int64_t n,
+template <class Key>
+int sort_pairs(Key *keys_in, Key *keys_out, float *vals_in, float *vals_out, int64_t n,
                unsigned end_bit, hipStream_t stream) {
     if (n == 0) return TGCN_OK;
     size_t tmp_bytes = 0;
@@ -271,6 +297,53 @@ int sort_pairs(uint64_t *keys_in, uint64_t *keys_out, float *vals_in, float *val
     TGCN_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
                                              static_cast<size_t>(n), 0u, end_bit, stream));
     TGCN_HIP_CHECK(hipStreamSynchronize(stream));  // tmp is freed on return
+    return TGCN_OK;
+}
+
+// The degree factors of gcn_norm over the WHOLE edge list: dis[n] = deg[n]^-1/2 (inf -> 0), loop_w[n] = the weight
+// of node n's self loop.  The one routine behind tgcn_plan_create and tgcn_gcn_norm, so that the single-device plan
+// and the per-rank operators of the 1-D partition are normalised by the SAME bits.  `loop_eid` is k_scan_edges'
+// result (1 + the edge id of the last input loop per node, 0 = none).  Scratch is O(chunk) + O(N); the stream is
+// synchronised (scratch is freed on return).
+int degree_factors(int64_t N, int64_t n_cols, int64_t E, const int64_t *src, int64_t ss, const int64_t *dst,
+                   int64_t ds, const float *w, int add_loops, int reference,
+                   const unsigned long long *loop_eid, float *dis, float *loop_w, hipStream_t stream) {
+    const char *cs = std::getenv("TGCN_NORM_CHUNK");
+    int64_t chunk = cs ? std::atoll(cs) : (int64_t(1) << 25);           // 32 M edges: 512 MB of sort scratch
+    chunk = std::max<int64_t>(1024, std::min<int64_t>(chunk, (int64_t(1) << 31) - 2));
+    const int64_t cap = std::min(chunk, std::max<int64_t>(E, 1));
+    DevBuf keys_a, keys_b, vals_a, vals_b, rowptr, deg;
+    TGCN_CHECK(keys_a.alloc(sizeof(uint32_t) * cap));
+    TGCN_CHECK(keys_b.alloc(sizeof(uint32_t) * cap));
+    TGCN_CHECK(vals_a.alloc(sizeof(float) * cap));
+    TGCN_CHECK(vals_b.alloc(sizeof(float) * cap));
+    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(deg.alloc((reference ? sizeof(float) : sizeof(double)) * N));
+    TGCN_HIP_CHECK(hipMemsetAsync(deg.p, 0, deg.bytes, stream));
+    unsigned node_bits = 1;
+    while ((int64_t(1) << node_bits) <= N) ++node_bits;                // the drop key N must sort too
+    for (int64_t lo = 0; lo < E; lo += chunk) {
+        const int64_t n = std::min(chunk, E - lo);
+        k_deg_keys<<<grid_for(n, kThreads, 8192), kThreads, 0, stream>>>(lo, n, src, ss, dst, ds, w, N, n_cols, add_loops,
+                                                                        keys_a.as<uint32_t>(), vals_a.as<float>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        // stable: the entries of a row keep their edge order (what the reference-order sum needs)
+        TGCN_CHECK(sort_pairs(keys_a.as<uint32_t>(), keys_b.as<uint32_t>(), vals_a.as<float>(), vals_b.as<float>(), n,
+                              node_bits, stream));
+        k_deg_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint32_t>(), n, N, rowptr.as<int32_t>());
+        TGCN_HIP_CHECK(hipGetLastError());
+        if (reference)
+            k_deg_sum_seq<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(rowptr.as<int32_t>(),
+                                                                                       vals_b.as<float>(), N, deg.as<float>());
+        else
+            k_deg_sum_f64<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(rowptr.as<int32_t>(),
+                                                                                       vals_b.as<float>(), N, deg.as<double>());
+        TGCN_HIP_CHECK(hipGetLastError());
+    }
+    k_deg_finish<<<grid_for(N), kThreads, 0, stream>>>(N, reference, deg.as<double>(), deg.as<float>(), add_loops,
+                                                       static_cast<float>(add_loops), loop_eid, w, dis, loop_w);
+    TGCN_HIP_CHECK(hipGetLastError());
+    TGCN_HIP_CHECK(hipStreamSynchronize(stream));   // scratch is freed on return
     return TGCN_OK;
 }
 
@@ -698,12 +771,6 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
     DevBuf loop_eid, flags, keys_a, keys_b, vals_a, vals_b, rowptr, rowptr_t, dis, cv, cv_t;
     TGCN_CHECK(loop_eid.alloc(sizeof(unsigned long long) * (add_loops ? N : 1)));
     TGCN_CHECK(flags.alloc(sizeof(unsigned int) * 4));
-    TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
-    TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
-    TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
-    TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
-    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
-    TGCN_CHECK(rowptr_t.alloc(sizeof(int32_t) * (n_cols + 1)));
     TGCN_CHECK(dis.alloc(sizeof(float) * N));
     TGCN_HIP_CHECK(hipMemsetAsync(loop_eid.p, 0, loop_eid.bytes ? loop_eid.bytes : 16, stream));
     TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
@@ -724,6 +791,17 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
     }
     const int64_t nnz = total - (add_loops ? int64_t(h_flags[1]) : 0);
 
+    // the degree factors come from the routine tgcn_gcn_norm uses too (its scratch is gone before the sort's is taken)
+    if (normalize && N > 0)
+        TGCN_CHECK(degree_factors(N, n_cols, E, src, ss, dst, ds, w, add_loops, normalize == 2,
+                                  loop_eid.as<unsigned long long>(), dis.as<float>(), nullptr, stream));
+    TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * total));
+    TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * total));
+    TGCN_CHECK(vals_a.alloc(sizeof(float) * total));
+    TGCN_CHECK(vals_b.alloc(sizeof(float) * total));
+    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
+    TGCN_CHECK(rowptr_t.alloc(sizeof(int32_t) * (n_cols + 1)));
+
     if (total > 0) {
         k_make_keys<<<grid_for(total, kThreads, 8192), kThreads, 0, stream>>>(
             E, src, ss, dst, ds, w, n_rows, n_cols, add_loops, static_cast<float>(add_loops),
@@ -743,11 +821,6 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
     k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), nnz, N,
                                                        rowptr.as<int32_t>());
     TGCN_HIP_CHECK(hipGetLastError());
-    if (normalize && N > 0) {
-        k_deg_inv_sqrt<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(
-            rowptr.as<int32_t>(), vals_b.as<float>(), N, dis.as<float>());
-        TGCN_HIP_CHECK(hipGetLastError());
-    }
     TGCN_CHECK(cv.alloc(sizeof(int2) * nnz));
     TGCN_CHECK(cv_t.alloc(sizeof(int2) * nnz));
     if (nnz > 0) {
@@ -860,6 +933,10 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64
         set_error("tgcn_plan_create: src/dst must be non-NULL with positive strides");
         return TGCN_E_INVALID;
     }
+    if (normalize < 0 || normalize > 2) {
+        set_error("tgcn_plan_create: normalize=%d must be TGCN_NORM_OFF, TGCN_NORM_ACCURATE or TGCN_NORM_REFERENCE", normalize);
+        return TGCN_E_INVALID;
+    }
     if (row_begin < 0 || row_end < row_begin || row_end > n_nodes) {
         set_error("tgcn_plan_create: row range [%lld, %lld) outside [0, %lld]", (long long)row_begin,
                   (long long)row_end, (long long)n_nodes);
@@ -879,7 +956,7 @@ int tgcn_plan_create(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64
     // PyG adds the loops inside gcn_norm, so GCNConv(normalize=False) never sees them
     // add_self_loops doubles as the fill weight: 1 -> 1.0, 2 -> 2.0 (GCNConv(improved=True))
     const int st = plan_create_impl(n_nodes, n_nodes, n_edges, src, src_stride, dst, dst_stride, w,
-                                    normalize != 0 ? std::max(0, std::min(add_self_loops, 2)) : 0, normalize != 0, 1,
+                                    normalize != 0 ? std::max(0, std::min(add_self_loops, 2)) : 0, normalize, 1,
                                     row_begin, row_end, static_cast<hipStream_t>(stream), *plan);
     if (st != TGCN_OK) {
         free_block(plan->fwd);
@@ -930,8 +1007,8 @@ int tgcn_plan_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
 }
 
 int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t src_stride,
-                  const int64_t *dst, int64_t dst_stride, const float *w, int add_self_loops, float *dis,
-                  float *loop_w, int device, tgcn_stream stream_) {
+                  const int64_t *dst, int64_t dst_stride, const float *w, int add_self_loops, int degree_sum,
+                  float *dis, float *loop_w, int device, tgcn_stream stream_) {
     using namespace tgcn;
     if (n_nodes <= 0 || n_edges < 0 || !dis) {
         set_error("tgcn_gcn_norm: need n_nodes > 0, n_edges >= 0 and a non-NULL dis");
@@ -939,6 +1016,10 @@ int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t 
     }
     if (n_edges > 0 && (!src || !dst || src_stride <= 0 || dst_stride <= 0)) {
         set_error("tgcn_gcn_norm: src/dst must be non-NULL with positive strides");
+        return TGCN_E_INVALID;
+    }
+    if (degree_sum != TGCN_DEGREE_ACCURATE && degree_sum != TGCN_DEGREE_REFERENCE) {
+        set_error("tgcn_gcn_norm: degree_sum=%d must be TGCN_DEGREE_ACCURATE or TGCN_DEGREE_REFERENCE", degree_sum);
         return TGCN_E_INVALID;
     }
     if (n_nodes >= (int64_t(1) << 31) - 1) {
@@ -950,19 +1031,9 @@ int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t N = n_nodes, E = n_edges;
     const int add_loops = std::max(0, std::min(add_self_loops, 2));
-    const char *cs = std::getenv("TGCN_NORM_CHUNK");
-    int64_t chunk = cs ? std::atoll(cs) : (int64_t(1) << 25);           // 32 M edges: 768 MB of sort scratch
-    chunk = std::max<int64_t>(1024, std::min<int64_t>(chunk, (int64_t(1) << 31) - 2));
-    const int64_t cap = std::min(chunk, std::max<int64_t>(E, 1));
-    DevBuf loop_eid, flags, keys_a, keys_b, vals_a, vals_b, rowptr, deg;
+    DevBuf loop_eid, flags;
     TGCN_CHECK(loop_eid.alloc(sizeof(unsigned long long) * (add_loops ? N : 1)));
     TGCN_CHECK(flags.alloc(sizeof(unsigned int) * 4));
-    TGCN_CHECK(keys_a.alloc(sizeof(uint64_t) * cap));
-    TGCN_CHECK(keys_b.alloc(sizeof(uint64_t) * cap));
-    TGCN_CHECK(vals_a.alloc(sizeof(float) * cap));
-    TGCN_CHECK(vals_b.alloc(sizeof(float) * cap));
-    TGCN_CHECK(rowptr.alloc(sizeof(int32_t) * (N + 1)));
-    TGCN_CHECK(deg.alloc(sizeof(double) * N));
     TGCN_HIP_CHECK(hipMemsetAsync(loop_eid.p, 0, loop_eid.bytes ? loop_eid.bytes : 16, stream));
     TGCN_HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, stream));
     if (E > 0) {
@@ -978,29 +1049,8 @@ int tgcn_gcn_norm(int64_t n_nodes, int64_t n_edges, const int64_t *src, int64_t 
         set_error("an index lies outside [0, %lld)", (long long)N);
         return TGCN_E_RANGE;
     }
-    k_norm_loops<<<grid_for(N), kThreads, 0, stream>>>(N, add_loops, static_cast<float>(add_loops),
-                                                       loop_eid.as<unsigned long long>(), w, loop_w, deg.as<double>());
-    TGCN_HIP_CHECK(hipGetLastError());
-    unsigned node_bits = 1;
-    while ((int64_t(1) << node_bits) <= N) ++node_bits;
-    for (int64_t lo = 0; lo < E; lo += chunk) {
-        const int64_t n = std::min(chunk, E - lo);
-        k_norm_keys<<<grid_for(n, kThreads, 8192), kThreads, 0, stream>>>(lo, n, src, src_stride, dst, dst_stride, w,
-                                                                         N, add_loops, keys_a.as<uint64_t>(),
-                                                                         vals_a.as<float>());
-        TGCN_HIP_CHECK(hipGetLastError());
-        TGCN_CHECK(sort_pairs(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<float>(), vals_b.as<float>(),
-                              n, 32 + node_bits, stream));
-        k_rowptr<<<grid_for(N + 1), kThreads, 0, stream>>>(keys_b.as<uint64_t>(), n, N, rowptr.as<int32_t>());
-        TGCN_HIP_CHECK(hipGetLastError());
-        k_norm_deg<<<grid_for(N, kThreads / 64, 1 << 20), kThreads, 0, stream>>>(rowptr.as<int32_t>(),
-                                                                                 vals_b.as<float>(), N, deg.as<double>());
-        TGCN_HIP_CHECK(hipGetLastError());
-    }
-    k_norm_dis<<<grid_for(N), kThreads, 0, stream>>>(N, deg.as<double>(), dis);
-    TGCN_HIP_CHECK(hipGetLastError());
-    TGCN_HIP_CHECK(hipStreamSynchronize(stream));   // scratch is freed on return
-    return TGCN_OK;
+    return degree_factors(N, N, E, src, src_stride, dst, dst_stride, w, add_loops, degree_sum == TGCN_DEGREE_REFERENCE,
+                          loop_eid.as<unsigned long long>(), dis, loop_w, stream);
 }
 
 int tgcn_plan_destroy(tgcn_plan *plan) {

@@ -8,6 +8,9 @@
 //                             zero, then one add into y) that every form of the exchange shares bit for bit.
 // One wavefront per row (64 float4 lanes cover 256 columns per pass); plain loads and stores: the rows are about to
 // be read by the SpMM (gather / scatter) or were just written by it (reduce).
+// Every entry point carries the row count of the indexed buffer: an index outside it is SKIPPED by the kernel (the
+// calls only enqueue, so they cannot report it) -- a wrong index list costs a wrong result, never a stray access.
+// pytextgcn_amd/sharded.py validates its lists once, when it builds them.
 #include <algorithm>
 
 #include "common.h"
@@ -38,12 +41,13 @@ constexpr int kRowWaves = 4;   // rows per 256-thread workgroup
 template <int VEC, bool SCATTER>
 __global__ __launch_bounds__(64 * kRowWaves) void k_rows_move(const float *__restrict__ src, int64_t lds_,
                                                              const int64_t *__restrict__ idx, int64_t n, int F,
-                                                             float *__restrict__ dst, int64_t ldd) {
+                                                             float *__restrict__ dst, int64_t ldd, int64_t n_indexed) {
     using vec_t = typename RowVec<VEC>::type;
     const int lane = threadIdx.x & 63;
     const int64_t stride = int64_t(gridDim.x) * kRowWaves;
     for (int64_t i = int64_t(blockIdx.x) * kRowWaves + (threadIdx.x >> 6); i < n; i += stride) {
         const int64_t j = idx[i];
+        if (j < 0 || j >= n_indexed) continue;                 // wave-uniform
         const float *s = src + (SCATTER ? i : j) * lds_;
         float *d = dst + (SCATTER ? j : i) * ldd;
         for (int c = lane * VEC; c < F; c += 64 * VEC)
@@ -53,8 +57,8 @@ __global__ __launch_bounds__(64 * kRowWaves) void k_rows_move(const float *__res
 
 template <int VEC>
 __global__ __launch_bounds__(64 * kRowWaves) void k_rows_reduce_ranked(const float *__restrict__ recv, int64_t ldr,
-                                                                      const int32_t *__restrict__ inv, int W,
-                                                                      int64_t n, int F, float *__restrict__ y,
+                                                                      int64_t n_recv, const int32_t *__restrict__ inv,
+                                                                      int W, int64_t n, int F, float *__restrict__ y,
                                                                       int64_t ldy, int64_t row0, int64_t step) {
     using V = RowVec<VEC>;
     using vec_t = typename V::type;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void k_rows_reduce_ranked(const flo
             vec_t acc = V::zero();
             for (int q = 0; q < W; ++q) {                      // rank order: the summation order of every exchange form
                 const int32_t i = inv[int64_t(q) * n + j];     // wave-uniform
-                if (i >= 0) acc = V::add(acc, *reinterpret_cast<const vec_t *>(recv + int64_t(i) * ldr + c));
+                if (i >= 0 && i < n_recv) acc = V::add(acc, *reinterpret_cast<const vec_t *>(recv + int64_t(i) * ldr + c));
             }
             *reinterpret_cast<vec_t *>(yr + c) = V::add(*reinterpret_cast<const vec_t *>(yr + c), acc);
         }
@@ -97,50 +101,56 @@ int check_rows(const char *fn, const void *a, const void *b, const void *idx, in
 
 extern "C" {
 
-int tgcn_rows_gather(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *out, int64_t ldo,
-                     tgcn_stream stream) {
+int tgcn_rows_gather(const float *x, int64_t ldx, int64_t n_x_rows, const int64_t *idx, int64_t n, int F, float *out,
+                     int64_t ldo, tgcn_stream stream) {
     using namespace tgcn;
     TGCN_CHECK(check_rows("tgcn_rows_gather", x, out, idx, n, F, ldx, ldo));
     if (n == 0) return TGCN_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec4_ok(F, ldx, ldo, x, out))
-        k_rows_move<4, false><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, out, ldo);
+        k_rows_move<4, false><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, out, ldo, n_x_rows);
     else
-        k_rows_move<1, false><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, out, ldo);
+        k_rows_move<1, false><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, out, ldo, n_x_rows);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }
 
 int tgcn_rows_scatter(const float *x, int64_t ldx, const int64_t *idx, int64_t n, int F, float *y, int64_t ldy,
-                      tgcn_stream stream) {
+                      int64_t n_y_rows, tgcn_stream stream) {
     using namespace tgcn;
     TGCN_CHECK(check_rows("tgcn_rows_scatter", x, y, idx, n, F, ldx, ldy));
     if (n == 0) return TGCN_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec4_ok(F, ldx, ldy, x, y))
-        k_rows_move<4, true><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, y, ldy);
+        k_rows_move<4, true><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, y, ldy, n_y_rows);
     else
-        k_rows_move<1, true><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, y, ldy);
+        k_rows_move<1, true><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(x, ldx, idx, n, F, y, ldy, n_y_rows);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }
 
-int tgcn_rows_reduce_ranked(const float *recv, int64_t ldr, const int32_t *inv, int n_ranks, int64_t n, int F,
-                            float *y, int64_t ldy, int64_t row0, int64_t row_step, tgcn_stream stream) {
+int tgcn_rows_reduce_ranked(const float *recv, int64_t ldr, int64_t n_recv_rows, const int32_t *inv, int n_ranks,
+                            int64_t n, int F, float *y, int64_t ldy, int64_t n_y_rows, int64_t row0, int64_t row_step,
+                            tgcn_stream stream) {
     using namespace tgcn;
-    if (n < 0 || F <= 0 || n_ranks <= 0 || ldr < F || ldy < F || row0 < 0 || row_step <= 0 ||
-        (n > 0 && (!inv || !y))) {
+    if (n < 0 || F <= 0 || n_ranks <= 0 || ldr < F || ldy < F || row0 < 0 || row_step <= 0 || n_recv_rows < 0 ||
+        (n > 0 && (!inv || !y)) || (n_recv_rows > 0 && !recv)) {
         set_error("tgcn_rows_reduce_ranked: bad argument (n=%lld F=%d ranks=%d ldr=%lld ldy=%lld row0=%lld step=%lld)",
                   (long long)n, F, n_ranks, (long long)ldr, (long long)ldy, (long long)row0, (long long)row_step);
         return TGCN_E_INVALID;
     }
     if (n == 0) return TGCN_OK;
+    if (row0 + (n - 1) * row_step >= n_y_rows) {
+        set_error("tgcn_rows_reduce_ranked: rows %lld + j * %lld, j < %lld, leave the %lld rows of y", (long long)row0,
+                  (long long)row_step, (long long)n, (long long)n_y_rows);
+        return TGCN_E_RANGE;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // recv may be NULL when no rank sent anything (every inv entry is then negative)
+    // recv may be NULL when no rank sent anything (n_recv_rows = 0: every table entry is then skipped)
     if (vec4_ok(F, ldr, ldy, recv, y))
-        k_rows_reduce_ranked<4><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(recv, ldr, inv, n_ranks, n, F, y, ldy, row0, row_step);
+        k_rows_reduce_ranked<4><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(recv, ldr, n_recv_rows, inv, n_ranks, n, F, y, ldy, row0, row_step);
     else
-        k_rows_reduce_ranked<1><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(recv, ldr, inv, n_ranks, n, F, y, ldy, row0, row_step);
+        k_rows_reduce_ranked<1><<<rows_grid(n), 64 * kRowWaves, 0, s>>>(recv, ldr, n_recv_rows, inv, n_ranks, n, F, y, ldy, row0, row_step);
     TGCN_HIP_CHECK(hipGetLastError());
     return TGCN_OK;
 }

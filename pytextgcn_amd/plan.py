@@ -27,14 +27,42 @@ def _require_cuda(t: Tensor, name: str) -> None:
             "through libtgcn.so (there is no CPU fallback)")
 
 
+# How a node's degree is summed by gcn_norm (include/tgcn.h, `normalize` of tgcn_plan_create):
+#   "accurate"   float64 sums rounded to fp32 once, and w * (dis[src] * dis[dst]): a symmetric graph stays bitwise
+#                symmetric.  The default: within fp32 rounding of the exact normalisation.
+#   "reference"  the bits of the reference's CPU path (PyG-1.6.3 gcn_norm as textgcn/lib/models.py:11-20 runs it): one fp32
+#                accumulator per node, weights added sequentially in edge order, the loop last, and PyG's association
+#                (dis[src] * w) * dis[dst].  On hub nodes with ~10^6 edges the sequential fp32 sum is a few 1e-5 (relative)
+#                off the exact degree -- choose this mode to reproduce the reference's numbers rather than the exact ones.
+_DEGREE_SUM = "accurate"
+
+
+def set_degree_sum(mode: str) -> str:
+    """Package default for plans built from now on ("accurate" | "reference"); returns the previous one."""
+    global _DEGREE_SUM
+    if mode not in _lib.DEGREE_SUMS:
+        raise ValueError(f"degree_sum must be one of {sorted(_lib.DEGREE_SUMS)}")
+    prev, _DEGREE_SUM = _DEGREE_SUM, mode
+    return prev
+
+
+def default_degree_sum() -> str:
+    return _DEGREE_SUM
+
+
 class GraphPlan:
     """M = D^-1/2 (A + I') D^-1/2 with M[target, source], rows [row_begin, row_end), kept in HBM
     as CSR with interleaved (col, val) pairs, plus M^T unless the operator is symmetric."""
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
                  add_self_loops=True, normalize: bool = True,
-                 row_range: Optional[Tuple[int, int]] = None):
+                 row_range: Optional[Tuple[int, int]] = None, degree_sum: Optional[str] = None):
         lib = _lib.load()
+        degree_sum = _DEGREE_SUM if degree_sum is None else degree_sum
+        if degree_sum not in _lib.DEGREE_SUMS:
+            raise ValueError(f"degree_sum must be one of {sorted(_lib.DEGREE_SUMS)}")
+        self.degree_sum = degree_sum if normalize else None
+        norm_mode = (_lib.NORM_REFERENCE if degree_sum == "reference" else _lib.NORM_ACCURATE) if normalize else _lib.NORM_OFF
         _require_cuda(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
@@ -56,7 +84,7 @@ class GraphPlan:
                 src.data_ptr() if n_edges else None, src.stride(0) if n_edges else 1,
                 dst.data_ptr() if n_edges else None, dst.stride(0) if n_edges else 1,
                 edge_weight.data_ptr() if edge_weight is not None else None,
-                int(add_self_loops), int(normalize), row_begin, row_end,
+                int(add_self_loops), norm_mode, row_begin, row_end,
                 self.device.index if self.device.index is not None else torch.cuda.current_device(),
                 _stream_ptr(self.device), ctypes.byref(handle)))
         self._adopt(lib, handle, n_cols=num_nodes, n_cols_t=num_nodes)
@@ -319,9 +347,9 @@ _PLAN_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 _PLAN_CACHE_MAX = 4
 
 
-def _key(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, loops: bool, norm: bool):
+def _key(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, loops: bool, norm: bool, degree_sum: str):
     k = (edge_index.device, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-         tuple(edge_index.stride()), edge_index.dtype, n, loops, norm)
+         tuple(edge_index.stride()), edge_index.dtype, n, loops, norm, degree_sum if norm else None)
     if edge_weight is not None:
         k += (edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape),
               edge_weight.dtype)
@@ -329,13 +357,14 @@ def _key(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, loops: bool,
 
 
 def plan_for(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-             add_self_loops: bool = True, normalize: bool = True) -> GraphPlan:
-    key = _key(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
+             add_self_loops: bool = True, normalize: bool = True, degree_sum: Optional[str] = None) -> GraphPlan:
+    degree_sum = _DEGREE_SUM if degree_sum is None else degree_sum
+    key = _key(edge_index, edge_weight, num_nodes, add_self_loops, normalize, degree_sum)
     hit = _PLAN_CACHE.get(key)
     if hit is not None:
         _PLAN_CACHE.move_to_end(key)
         return hit[0]
-    plan = GraphPlan(edge_index, edge_weight, num_nodes, add_self_loops, normalize)
+    plan = GraphPlan(edge_index, edge_weight, num_nodes, add_self_loops, normalize, degree_sum=degree_sum)
     _PLAN_CACHE[key] = (plan, edge_index, edge_weight)
     while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
         _PLAN_CACHE.popitem(last=False)

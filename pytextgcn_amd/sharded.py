@@ -43,11 +43,11 @@ from .conv import glorot_
 # --------------------------------------------------------------------------------------------------
 class HipEngine:
     def gcn_norm(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                 add_self_loops: int) -> Tuple[Tensor, Tensor]:
+                 add_self_loops: int, degree_sum: str = "accurate") -> Tuple[Tensor, Tensor]:
         """(dis, loop_w): deg^-1/2 per node (in-degree at the target incl. the self loop, inf -> 0) and the
         weight of every node's self loop, from the WHOLE edge list -- libtgcn.so `tgcn_gcn_norm`, which walks
-        the edges in bounded chunks: no whole-graph plan, no nnz-sized temporaries."""
-        import ctypes
+        the edges in bounded chunks: no whole-graph plan, no nnz-sized temporaries.  It is the routine
+        tgcn_plan_create itself runs, so the factors are bit for bit the single-device plan's."""
         from . import _lib
         from .plan import _require_cuda, _stream_ptr
         lib = _lib.load()
@@ -66,7 +66,8 @@ class HipEngine:
             _lib.check(lib.tgcn_gcn_norm(
                 num_nodes, n_edges, src.data_ptr() if n_edges else None, src.stride(0) if n_edges else 1,
                 dst.data_ptr() if n_edges else None, dst.stride(0) if n_edges else 1,
-                w.data_ptr() if w is not None else None, int(add_self_loops), dis.data_ptr(), loop_w.data_ptr(),
+                w.data_ptr() if w is not None else None, int(add_self_loops), _lib.DEGREE_SUMS[degree_sum],
+                dis.data_ptr(), loop_w.data_ptr(),
                 dev.index if dev.index is not None else torch.cuda.current_device(), _stream_ptr(dev)))
         return dis, loop_w
 
@@ -90,30 +91,59 @@ class HipEngine:
         from .functional import masked_cross_entropy
         return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
 
-    # row movement of the exchange (libtgcn.so `tgcn_rows_*`, csrc/rows.hip)
+    # row movement of the exchange (libtgcn.so `tgcn_rows_*`, csrc/rows.hip).  The C ABI takes raw pointers: what
+    # they must point at is asserted here (the library additionally skips indices outside the row counts it is given)
+    @staticmethod
+    def _rows_ok(x: Tensor, name: str) -> None:
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and (x.size(1) == 0 or x.stride(1) == 1)):
+            raise TypeError(f"{name}: a float32 [rows, F] device matrix with unit column stride is required, got "
+                            f"{x.dtype} {tuple(x.shape)} strides {tuple(x.stride())} on {x.device}")
+
+    @staticmethod
+    def _index_ok(idx: Tensor, like: Tensor, name: str, dtype=torch.int64) -> None:
+        if not (idx.is_cuda and idx.device == like.device and idx.dtype == dtype and idx.is_contiguous()):
+            raise TypeError(f"{name}: a contiguous {dtype} index tensor on {like.device} is required, got "
+                            f"{idx.dtype} (contiguous: {idx.is_contiguous()}) on {idx.device}")
+
     def rows_gather(self, x: Tensor, idx: Tensor) -> Tensor:
         """x[idx] (rows), packed for sending."""
         from . import _lib
         from .plan import _stream_ptr
+        self._rows_ok(x, "rows_gather: x")
+        self._index_ok(idx, x, "rows_gather: idx")
         out = torch.empty(idx.numel(), x.size(1), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().tgcn_rows_gather(x.data_ptr(), x.stride(0), idx.data_ptr(), idx.numel(), x.size(1),
-                                                out.data_ptr(), out.stride(0), _stream_ptr(x.device)))
+        _lib.check(_lib.load().tgcn_rows_gather(x.data_ptr(), x.stride(0), x.size(0), idx.data_ptr(), idx.numel(),
+                                                x.size(1), out.data_ptr(), out.stride(0), _stream_ptr(x.device)))
         return out
 
     def rows_scatter_(self, y: Tensor, idx: Tensor, x: Tensor) -> None:
         """y[idx] = x (rows; idx distinct)."""
         from . import _lib
         from .plan import _stream_ptr
+        self._rows_ok(x, "rows_scatter_: x")
+        self._rows_ok(y, "rows_scatter_: y")
+        self._index_ok(idx, y, "rows_scatter_: idx")
+        if x.size(0) != idx.numel() or x.size(1) != y.size(1) or x.device != y.device:
+            raise ValueError(f"rows_scatter_: {tuple(x.shape)} rows for {idx.numel()} indices into {tuple(y.shape)}")
         _lib.check(_lib.load().tgcn_rows_scatter(x.data_ptr(), x.stride(0), idx.data_ptr(), idx.numel(), x.size(1),
-                                                 y.data_ptr(), y.stride(0), _stream_ptr(y.device)))
+                                                 y.data_ptr(), y.stride(0), y.size(0), _stream_ptr(y.device)))
 
     def reduce_ranked_(self, y: Tensor, recv: Tensor, inv: Tensor, n_ranks: int, n: int, row0: int, step: int) -> None:
         """y[row0 + j * step] += sum over ranks q, in order, of recv[inv[q, j]] (inv < 0: nothing from q), j < n."""
         from . import _lib
         from .plan import _stream_ptr
+        self._rows_ok(y, "reduce_ranked_: y")
+        self._index_ok(inv, y, "reduce_ranked_: inv", torch.int32)
+        if inv.numel() != n_ranks * n:
+            raise ValueError(f"reduce_ranked_: the table has {inv.numel()} entries for {n_ranks} ranks x {n} rows")
+        if recv.numel():
+            self._rows_ok(recv, "reduce_ranked_: recv")
+            if recv.size(1) != y.size(1) or recv.device != y.device:
+                raise ValueError("reduce_ranked_: recv and y differ in width or device")
         _lib.check(_lib.load().tgcn_rows_reduce_ranked(
-            recv.data_ptr() if recv.numel() else None, recv.stride(0) if recv.numel() else y.size(1), inv.data_ptr(),
-            n_ranks, n, y.size(1), y.data_ptr(), y.stride(0), row0, step, _stream_ptr(y.device)))
+            recv.data_ptr() if recv.numel() else None, recv.stride(0) if recv.numel() else y.size(1),
+            recv.size(0) if recv.numel() else 0, inv.data_ptr(), n_ranks, n, y.size(1), y.data_ptr(), y.stride(0),
+            y.size(0), row0, step, _stream_ptr(y.device)))
 
 
 class _Done:
@@ -247,17 +277,98 @@ class ShardedGraph:
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
                  group=None, hubs: Optional[Tensor] = None, add_self_loops=True,
-                 normalize: bool = True, engine=None, symmetric: Optional[bool] = None):
+                 normalize: bool = True, engine=None, symmetric: Optional[bool] = None,
+                 degree_sum: Optional[str] = None):
         """`symmetric`: None = find out (an edge-multiset fingerprint of M against M^T); True / False skips
         the test (TextGCN graphs are symmetric by construction, text2graph.py:148-171).
+        `degree_sum`: "accurate" (float64 degree sums, symmetric association -- the default) or "reference" (PyG's
+        sequential fp32 sums in edge order and its association: the reference's bits; the operator is then not
+        bitwise symmetric and M^T gets its own operators).  None = the package default (pytextgcn_amd.set_degree_sum).
+        Either way the weights are bit for bit the single-device plan's of the same mode.
         Construction is COLLECTIVE: every rank of `group` must build the graph at the same time (the index lists of
         the halo exchange are swapped between the ranks)."""
         self.group = group if group is not None else dist.group.WORLD
-        self.world = dist.get_world_size(self.group)
-        self.rank = dist.get_rank(self.group)
+        self._setup(edge_index, edge_weight, num_nodes, dist.get_world_size(self.group), dist.get_rank(self.group),
+                    hubs, add_self_loops, normalize, engine, symmetric, degree_sum)
+        # Forms of the exchange (all give the same sums; "p2p" and "halo" add the ranks' partial rows in rank order,
+        # bit for bit alike; RCCL's reduce-scatter adds them in an order of its own):
+        #   "collective"  RCCL all-gather + reduce-scatter of the whole hub block;
+        #   "p2p"         the same rows as direct pairwise transfers (batched send / recv, all-to-all + local sum):
+        #                 on a full xGMI mesh every pair of GPUs has its own link;
+        #   "halo"        index lists built here, once: a rank receives only the hub rows its B_r references and sends
+        #                 only the partial rows its A_r touches (all_to_all_single with split sizes).  For graphs
+        #                 without hub structure (hubs=None) this is the true halo exchange.
+        # TGCN_EXCHANGE pins the form, TGCN_RS_CHUNKS the number of row chunks A_r runs in (each chunk's
+        # reduce-scatter starts when its rows are finished); bench.py times a few steps of each and keeps the fastest.
+        import os
+        self._build_halo_lists()
+        self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
+        self.exchange = os.environ.get("TGCN_EXCHANGE", "collective")
+        if self.exchange not in self.EXCHANGES:
+            raise ValueError(f"TGCN_EXCHANGE must be one of {self.EXCHANGES}")
+
+    @classmethod
+    def for_rank(cls, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, world: int, rank: int,
+                 hubs: Optional[Tensor] = None, add_self_loops=True, normalize: bool = True, engine=None,
+                 symmetric: Optional[bool] = None, degree_sum: Optional[str] = None,
+                 halo_lists: bool = False) -> "ShardedGraph":
+        """What rank `rank` of a `world`-rank group would build, WITHOUT a process group: the partition, the
+        normalisation and the local operators A_r / B_r (`ops`, `dirs`), cut exactly as the collective constructor
+        cuts them, plus `need_cols` (the gathered-block rows its B_r reads) and, with `halo_lists`, the gather-side
+        lists of the halo exchange (`_build_halo_lists_offline`).  What needs the peers (`spmm`, the reduce-side lists)
+        is absent.  For inspecting and timing one rank's share of a partition on a single
+        device -- tests at BASELINE size, tools/sim_shard_compute.py."""
+        self = cls.__new__(cls)
+        self.group = None
+        self._setup(edge_index, edge_weight, num_nodes, int(world), int(rank), hubs, add_self_loops, normalize, engine,
+                    symmetric, degree_sum)
+        self.exchange = "collective"
+        if halo_lists:
+            self._build_halo_lists_offline(edge_index)
+        return self
+
+    def _build_halo_lists_offline(self, edge_index: Tensor) -> None:
+        """The gather-side lists of the halo exchange as `_build_halo_lists` leaves them, computed WITHOUT the peers:
+        which gathered-block rows every rank's B_q reads follows from the partition and the edge list alone (one pass,
+        a [W, W * hp] table of flags), so the slots this rank would be asked for are known without asking."""
+        p, W, hp, r = self.part, self.world, self.hp, self.rank
+        dev = edge_index.device
+        for k, d in enumerate(self.dirs):
+            asked = torch.zeros(W, hp, dtype=torch.bool, device=dev)          # asked[q, s]: rank q reads own hub slot s
+            E = edge_index.size(1)
+            for lo in range(0, E, self._CHUNK):
+                s, t = edge_index[0, lo:lo + self._CHUNK], edge_index[1, lo:lo + self._CHUNK]
+                if k == 1:
+                    s, t = t, s
+                if self._loops:
+                    keep = s != t
+                    s, t = s[keep], t[keep]
+                sel = p.hub_mask[s] & (p.owner[s] == r)                       # B_q reads hub columns only from the block
+                asked[p.owner[t[sel]], p.slot[s[sel]]] = True
+            if self._loops:
+                own_hub = self.owned[:hp][self.real[:hp]]
+                asked[r, p.slot[own_hub]] = True                              # the own hubs' loops
+            q_idx, slots = torch.nonzero(asked, as_tuple=True)                 # rank-major, slots ascending
+            d.send_slots, d.send_counts = slots.contiguous(), torch.bincount(q_idx, minlength=W)
+            owner = d.need_cols // hp
+            d.need_counts = torch.bincount(owner, minlength=W)
+            d.need_counts_l = [int(v) for v in d.need_counts.tolist()]
+            d.send_counts_l = [int(v) for v in d.send_counts.tolist()]
+
+    def _setup(self, edge_index, edge_weight, num_nodes, world, rank, hubs, add_self_loops, normalize, engine, symmetric,
+               degree_sum) -> None:
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside a world of {world}")
+        self.world, self.rank = world, rank
         self.engine = engine if engine is not None else HipEngine()
         self.num_nodes = num_nodes
         self.device = edge_index.device
+        if degree_sum is None:
+            from .plan import default_degree_sum
+            degree_sum = default_degree_sum()
+        if degree_sum not in ("accurate", "reference"):
+            raise ValueError('degree_sum must be "accurate" or "reference"')
+        self.degree_sum = degree_sum
         part = Partition(edge_index, num_nodes, self.world, hubs)
         self.part = part
         self.hp, self.rp, self.n_local = part.hp, part.rp, part.n_local
@@ -273,7 +384,10 @@ class ShardedGraph:
         loops = (max(0, min(int(add_self_loops), 2)) if normalize else 0)
         self._dis = self._loop_w = None
         if normalize:
-            self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops)
+            if degree_sum == "accurate":          # (test engines predate the argument; the default needs none)
+                self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops)
+            else:
+                self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops, degree_sum)
         self._loops = loops
         self.symmetric = bool(symmetric) if symmetric is not None else \
             self._is_symmetric(edge_index, edge_weight)
@@ -282,23 +396,7 @@ class ShardedGraph:
             self.dirs.append(self._local_ops(edge_index, edge_weight, transpose=True))
         self._dis = self._loop_w = None
         self.plan = self.dirs[0].B            # the larger local operator (for reporting)
-        # Forms of the exchange (all give the same sums; "p2p" and "halo" add the ranks' partial rows in rank order,
-        # bit for bit alike; RCCL's reduce-scatter adds them in an order of its own):
-        #   "collective"  RCCL all-gather + reduce-scatter of the whole hub block;
-        #   "p2p"         the same rows as direct pairwise transfers (batched send / recv, all-to-all + local sum):
-        #                 on a full xGMI mesh every pair of GPUs has its own link;
-        #   "halo"        index lists built here, once: a rank receives only the hub rows its B_r references and sends
-        #                 only the partial rows its A_r touches (all_to_all_single with split sizes).  For graphs
-        #                 without hub structure (hubs=None) this is the true halo exchange.
-        # TGCN_EXCHANGE pins the form, TGCN_RS_CHUNKS the number of row chunks A_r runs in (each chunk's
-        # reduce-scatter starts when its rows are finished); bench.py times a few steps of each and keeps the fastest.
-        import os
-        self._build_halo_lists()
         self.rs_chunks = 1
-        self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
-        self.exchange = os.environ.get("TGCN_EXCHANGE", "collective")
-        if self.exchange not in self.EXCHANGES:
-            raise ValueError(f"TGCN_EXCHANGE must be one of {self.EXCHANGES}")
         self._xbuf = {}
         self._stage = {}
 
@@ -319,9 +417,9 @@ class ShardedGraph:
     # ---- construction ---------------------------------------------------------------------------
     def _chunks(self, edge_index: Tensor, edge_weight: Optional[Tensor]):
         """(source, target, w_hat) of the non-loop entries of M, a chunk of edges at a time: w_hat = w * (dis[s]
-        * dis[t]) -- the association of tgcn_plan_create, which keeps a symmetric graph bitwise symmetric.  (The
-        degrees behind `dis` are summed chunk-wise by tgcn_gcn_norm, so the weights agree with the single-device
-        plan's to fp32 rounding, not bit for bit.)"""
+        * dis[t]) -- the association of tgcn_plan_create, which keeps a symmetric graph bitwise symmetric ((dis[s] *
+        w) * dis[t] in the reference-order mode).  `dis` comes from the routine tgcn_plan_create runs itself and the
+        products are the same IEEE multiplications, so the weights are the single-device plan's bit for bit."""
         E = edge_index.size(1)
         for lo in range(0, E, self._CHUNK):
             hi = min(E, lo + self._CHUNK)
@@ -332,7 +430,10 @@ class ShardedGraph:
                 keep = s != t
                 s, t, w = s[keep], t[keep], w[keep]
             if self._dis is not None:
-                w = w * (self._dis[s] * self._dis[t])
+                if self.degree_sum == "reference":             # PyG's association (gcn_conv.py: dis[row] * w * dis[col])
+                    w = (self._dis[s] * w) * self._dis[t]
+                else:
+                    w = w * (self._dis[s] * self._dis[t])
             yield s, t, w
 
     def _is_symmetric(self, edge_index: Tensor, edge_weight: Optional[Tensor]) -> bool:
@@ -378,7 +479,10 @@ class ShardedGraph:
             need[lcol[own_hub]] = True
             lw = self._loop_w[own]
             if self._dis is not None:
-                lw = lw * (self._dis[own] * self._dis[own])
+                if self.degree_sum == "reference":
+                    lw = (self._dis[own] * lw) * self._dis[own]
+                else:
+                    lw = lw * (self._dis[own] * self._dis[own])
             parts_b.append((lrow, lcol, lw))
 
         def cat(parts, k):
@@ -420,6 +524,19 @@ class ShardedGraph:
             d.send_slots, d.send_counts = self._swap_lists(d.need_cols - owner * hp, d.need_counts)
             d.need_counts_l = [int(v) for v in d.need_counts.tolist()]
             d.send_counts_l = [int(v) for v in d.send_counts.tolist()]
+            # the row-movement kernels take these lists as raw pointers: check them once, here
+            self._check_list(d.send_slots, hp, "send_slots")                  # rows of the own shard
+            self._check_list(d.need_cols, W * hp, "need_cols", distinct=True)  # rows of the gathered block
+
+    @staticmethod
+    def _check_list(idx: Tensor, n_rows: int, name: str, distinct: bool = False) -> None:
+        if idx.numel() == 0:
+            return
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n_rows:
+            raise IndexError(f"sharded: index list `{name}` spans [{lo}, {hi}] for a buffer of {n_rows} rows")
+        if distinct and int(torch.unique(idx).numel()) != idx.numel():
+            raise ValueError(f"sharded: index list `{name}` holds a row twice")
 
     def set_rs_chunks(self, K: int) -> None:
         """Run A_r as K row chunks (hub slot s belongs to chunk s % K, so the chunks are alike in weight); the
@@ -458,9 +575,21 @@ class ShardedGraph:
                 src = torch.repeat_interleave(torch.arange(W, device=self.device), got_counts.to(self.device))
                 inv[src, got] = torch.arange(got.numel(), dtype=torch.int32, device=self.device)
                 ch.inv_halo = inv[:, :n_own].contiguous()
+                self._check_list(touched, W * ch.ck, "touch_rows", distinct=True)   # rows of the chunk's partial sums
+                self._check_list(got, max(n_own, 1), "recv_pos")
                 ar = torch.arange(n_own, dtype=torch.int32, device=self.device)
                 ch.inv_dense = (torch.arange(W, dtype=torch.int32, device=self.device).unsqueeze(1) * ch.ck + ar).contiguous()
         self.rs_chunks = K
+
+    def drop_unused_chunks(self) -> None:
+        """Release the A_r row-chunk operators of every chunk count but the current one (bench.py builds K = 1, 2, 4
+        to time them; the losers are dead weight afterwards).  `A_entries` stay, so another count can be cut again."""
+        for d in self.dirs:
+            for K in [k for k in d.chunks if k != self.rs_chunks and k != 1]:
+                for ch in d.chunks.pop(K):
+                    close = getattr(ch.op, "close", None)
+                    if close is not None:
+                        close()
 
     # ---- data movement ---------------------------------------------------------------------------
     def scatter_rows(self, full: Tensor) -> Tensor:
@@ -505,7 +634,10 @@ class ShardedGraph:
 
     _NARROW = 128     # widths up to here run the sub-group SpMM kernels, which take ONE operand buffer
 
-    def _gather_buffer(self, x_local: Tensor, halo: bool) -> Tensor:
+    def _xbuf_key(self, x_local: Tensor, halo: bool, d: Optional["_Direction"]):
+        return (x_local.size(1), x_local.dtype, x_local.device, halo, self.dirs.index(d) if (halo and d is not None) else 0)
+
+    def _gather_buffer(self, x_local: Tensor, halo: bool, d: Optional[_Direction] = None) -> Tensor:
         """The gathered hub block [W * hp, F], one per width (layer-1 / layer-2 widths alternate).  The halo form
         has its own, zero-filled once: it only ever writes the rows B_r references, and the rest must stay finite
         (the dense hot block of a local operator multiplies EVERY operand row by a possibly zero weight).
@@ -513,7 +645,10 @@ class ShardedGraph:
         own regular rows] in one buffer, which is what the sub-group kernels gather from (the copy of the own rows
         is rp x F floats; at wide widths B_r reads them in place as a split operand)."""
         F = x_local.size(1)
-        key = (F, x_local.dtype, x_local.device, halo)
+        # the halo form writes only the rows the direction's B_r references: M and M^T of an asymmetric graph read
+        # different rows, so each direction keeps its own block (a row left over from the other direction would be
+        # multiplied by a zero weight of the dense hot block -- harmless only while it is finite)
+        key = self._xbuf_key(x_local, halo, d)
         xbuf = self._xbuf.get(key)
         if xbuf is None:
             make = torch.zeros if halo else torch.empty
@@ -522,11 +657,11 @@ class ShardedGraph:
             self._xbuf[key] = xbuf
         return xbuf[:self.world * self.hp]
 
-    def _whole_operand(self, xbuf: Tensor, x_local: Tensor) -> Optional[Tensor]:
+    def _whole_operand(self, d: _Direction, x_local: Tensor) -> Optional[Tensor]:
         """[gathered hubs ; own regular rows] as one tensor when the width calls for it (see _gather_buffer)."""
         if self.rp == 0 or x_local.size(1) > self._NARROW:
             return None
-        whole = self._xbuf[(x_local.size(1), x_local.dtype, x_local.device, self.exchange == "halo")]
+        whole = self._xbuf[self._xbuf_key(x_local, self.exchange == "halo", d)]
         whole[self.world * self.hp:].copy_(x_local[self.hp:])
         return whole
 
@@ -545,7 +680,7 @@ class ShardedGraph:
             works = self._all_gather_p2p(xbuf, shard) if direct else self._all_gather_p2p_staged(xbuf, shard)
             return xbuf, lambda: [w.wait() for w in works]
         # halo: only the rows somebody reads travel
-        xbuf = self._gather_buffer(x_local, True)
+        xbuf = self._gather_buffer(x_local, True, d)
         pack = self._rows_gather(shard, d.send_slots)
         recv, work = self._all_to_all_v(pack, d.need_counts_l, d.send_counts_l, direct)
 
@@ -648,7 +783,7 @@ class ShardedGraph:
             xr = x_local[hp:]
             for ch in d.chunks[self.rs_chunks]:
                 pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
-        whole = self._whole_operand(xbuf, x_local)             # narrow widths: own rows copied behind the hub block
+        whole = self._whole_operand(d, x_local)                # narrow widths: own rows copied behind the hub block
         gathered()
         if whole is not None:
             y = d.B.spmm(whole, bias)                                       # overlaps the reduce-scatter

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
@@ -24,3 +26,17 @@ def cuda():
         build.build()
     _lib.load()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def c4case(cuda):
+    """Config c4 (2 M nodes / 50 M edges) and the oracle's normalisation of it, shared by the tests of one session."""
+    from _bigcase import BigCase
+    return BigCase("c4", cuda)
+
+
+@pytest.fixture(scope="session")
+def c5case(cuda):
+    """Config c5 (8 M nodes / 200 M edges, power law) likewise."""
+    from _bigcase import BigCase
+    return BigCase("c5", cuda)

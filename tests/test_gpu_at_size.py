@@ -1,0 +1,292 @@
+"""BASELINE-size checks that need the oracle's normalisation of the whole graph (tests/_bigcase.py, shared per session):
+
+  * the reference-order normalisation mode (`degree_sum="reference"`) on config c4: the plan's weights are the fp32
+    oracle's BIT FOR BIT and the whole two-layer eval forward meets BASELINE.json's 1e-5 against the fp32 oracle;
+  * the 1-D partition at size (c4 over 8 ranks with the word nodes as hubs; c5 over 8 ranks without hub structure):
+    the local operators of the first and the last rank, cut exactly as the collective constructor cuts them
+    (`ShardedGraph.for_rank`), against the oracle's operator entry by entry and row by row, the nnz balance, the index
+    lists of the halo exchange against a recomputation from the edge list, and the default mode's weights against the
+    single-device plan's bit for bit.
+
+The reference is single-device (flat_amazon.py:84-86): the partition has nothing there to mirror, so the oracle of the
+partitioned form is the oracle of the whole operator, restricted to the rows and columns a rank owns."""
+import pytest
+import torch
+
+from oracle import csr_oracle
+import pytextgcn_amd as pkg
+from pytextgcn_amd.plan import GraphPlan
+from pytextgcn_amd.sharded import ShardedGraph
+
+from test_gpu_parity import TOL, _report, rel_err, row_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference-order mode at c4
+# ------------------------------------------------------------------------------------------------
+def test_config_c4_reference_order_mode_reproduces_the_oracles_weights_and_meets_1e5(cuda, c4case):
+    """`degree_sum="reference"`: PyG's CPU arithmetic (one fp32 accumulator per node, weights in edge order, the loop
+    last; (dis[src] * w) * dis[dst]) -- what textgcn/lib/models.py:11-20 executes.  All 52 M weights of the c4 plan
+    equal the oracle's bit for bit, M^T is stored (PyG's association is not symmetric), and the eval forward of
+    GCN(N -> 200 -> 64) over all 2 M rows is within 1e-5 of the fp32 oracle's network (the default mode is 1.3e-5 from
+    it because the oracle's hub degrees are)."""
+    N, F, C = c4case.N, 200, 64
+    g = c4case.g
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="reference")
+    rp_ref, col_ref, val_ref, _ = c4case.oracle_csr()
+    rp, col, val = plan.export_csr()
+    assert torch.equal(rp.cpu().long(), rp_ref) and torch.equal(col.cpu(), col_ref)
+    v = val.cpu()
+    n_diff = int((v.view(torch.int32) != val_ref.view(torch.int32)).sum())
+    worst = float(((v.double() - val_ref.double()).abs() / val_ref.double()).max())
+    _report("c4_reference_mode_weights", entries=int(v.numel()), entries_differing_in_any_bit=n_diff,
+            worst_relative_difference=worst)
+    assert n_diff == 0, (n_diff, worst)
+    assert not plan.symmetric and plan.has_transpose           # (dis[s] * w) * dis[t] rounds (i, j) and (j, i) apart
+    del rp, col, val, v
+    # the transposed block holds the same weights, transposed: <M x, y> = <x, M^T y>
+    gen = torch.Generator(device=cuda).manual_seed(12)
+    x = torch.randn(N, 8, device=cuda, generator=gen)
+    y = torch.randn(N, 8, device=cuda, generator=gen)
+    lhs = (plan.spmm(x).double() * y.double()).sum().item()
+    rhs = (x.double() * plan.spmm(y, transpose=True).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-6
+    del x, y
+    # the whole eval forward against the fp32 ORACLE's network, all rows, at the 1e-5 bar
+    prev = pkg.set_degree_sum("reference")
+    try:
+        torch.manual_seed(7)
+        model = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.5).to(cuda).float().eval()
+        with torch.no_grad():
+            model.layers[0].bias.normal_(0, 0.1)
+            model.layers[1].bias.normal_(0, 0.1)
+            ar = torch.arange(N, device=cuda)
+            eye = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=cuda), (N, N)).coalesce()
+            logits = model(pkg.Data(x=eye, edge_index=g.edge_index, edge_attr=g.edge_attr)).cpu()
+            w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
+                                                         model.layers[1].weight, model.layers[1].bias))
+    finally:
+        pkg.set_degree_sum(prev)
+    h1 = csr_oracle.csr_spmm(rp_ref, col_ref, val_ref, w1, b1, acc64=True)
+    xw2 = (h1.double() @ w2.double()).float()
+    want = csr_oracle.csr_spmm(rp_ref, col_ref, val_ref, xw2, b2, acc64=True)
+    e, e_row = rel_err(logits, want), row_rel_err(logits, want)
+    _report("c4_eval_forward_reference_mode", plan_vs_fp32_oracle=e, plan_vs_fp32_oracle_row_relative=e_row)
+    assert e < TOL and e_row < TOL, (e, e_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# the 1-D partition at size
+# ------------------------------------------------------------------------------------------------
+def _expected_local_csr(sg, tgt, src, val, which, transpose=False):
+    """Rank sg.rank's local operator written down directly from the WHOLE operator's entries (target, source, value
+    -- device tensors, PyG order): A_r = hub rows (gathered numbering) x own regular columns, B_r = own rows x (all hubs
+    + own regular columns), module docstring of pytextgcn_amd/sharded.py.  CSR with a row's entries by column, ties in
+    the order given."""
+    p, r, hp, rp, W = sg.part, sg.rank, sg.hp, sg.rp, sg.world
+    if transpose:
+        tgt, src = src, tgt
+    t_hub, s_hub = p.hub_mask[tgt], p.hub_mask[src]
+    t_mine, s_mine = p.owner[tgt] == r, p.owner[src] == r
+    if which == "A":
+        sel = t_hub & ~s_hub & s_mine
+        t, s = tgt[sel], src[sel]
+        row, col, n_rows, n_cols = p.hub_col[t], p.slot[s], W * hp, rp
+    else:
+        sel = t_mine & (s_hub | (s_mine & ~t_hub))
+        t, s = tgt[sel], src[sel]
+        row = torch.where(p.hub_mask[t], p.slot[t], hp + p.slot[t])
+        col = torch.where(p.hub_mask[s], p.hub_col[s], p.reg_col[s])
+        n_rows, n_cols = hp + rp, W * hp + rp
+    order = torch.argsort(row * n_cols + col, stable=True)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=row.device)
+    rowptr[1:] = torch.bincount(row, minlength=n_rows).cumsum(0)
+    return rowptr, col[order], val[sel][order]
+
+
+def _assert_op_equals(op, expect, bitwise=True):
+    rp, col, val = op.export_csr()
+    e_rp, e_col, e_val = expect
+    assert torch.equal(rp.long(), e_rp)
+    assert torch.equal(col.long(), e_col)
+    if bitwise:
+        n_diff = int((val.view(torch.int32) != e_val.view(torch.int32)).sum())
+        assert n_diff == 0, (n_diff, float((val - e_val).abs().max()))
+    else:
+        assert float((val.double() - e_val.double()).abs().max()) <= 2e-6 * float(e_val.abs().max())
+
+
+def _rows_of_csr(rp, col, val, rows, keep_col=None):
+    """Sub-CSR (host) of the listed rows of a host CSR, optionally keeping only the entries whose column passes
+    `keep_col` (a bool tensor over the columns)."""
+    lo, n = rp[rows], rp[rows + 1] - rp[rows]
+    start = torch.zeros(rows.numel() + 1, dtype=torch.int64)
+    start[1:] = n.cumsum(0)
+    pos = torch.arange(int(start[-1])) - torch.repeat_interleave(start[:-1], n) + torch.repeat_interleave(lo, n)
+    c, v = col[pos], val[pos]
+    if keep_col is None:
+        return start, c.contiguous(), v.contiguous()
+    keep = keep_col[c.long()]
+    rid = torch.repeat_interleave(torch.arange(rows.numel()), n)[keep]
+    out_rp = torch.zeros(rows.numel() + 1, dtype=torch.int64)
+    out_rp[1:] = torch.bincount(rid, minlength=rows.numel()).cumsum(0)
+    return out_rp, c[keep].contiguous(), v[keep].contiguous()
+
+
+def test_config_c4_eight_rank_partition_first_and_last_rank_against_the_oracle(cuda, c4case):
+    """c4 over 8 ranks, word nodes as hubs (BASELINE.json configs[3]): ranks 0 and 7 in the reference-order mode --
+    A_r and B_r equal the oracle's entries bit for bit; A_r @ X_reg and B_r @ [X_hub ; X_reg] against the C CSR oracle
+    on the ORACLE's rows (document rows: the whole row; hub rows: the columns the operator holds) at 1e-5, also per
+    row; every node owned exactly once; non-zeros balanced to 2 %.  Rank 0 once more in the default mode: its weights
+    are the single-device plan's bit for bit."""
+    N, F, W = c4case.N, 200, 8
+    g = c4case.g
+    V = g.n_vocab
+    hubs = torch.arange(N, device=cuda) < V
+    tgt, src, nw = (t.to(cuda) for t in c4case.oracle_coo())
+    rp_ref, col_ref, val_ref, _ = c4case.oracle_csr()
+    gen = torch.Generator(device=cuda).manual_seed(21)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    bias = torch.randn(F, device=cuda, generator=gen)
+    x_cpu = x.cpu()
+    nnz = {}
+    for r in (0, W - 1):
+        sg = ShardedGraph.for_rank(g.edge_index, g.edge_attr, N, W, r, hubs=hubs, degree_sum="reference")
+        p, hp, rp_ = sg.part, sg.hp, sg.rp
+        assert not sg.symmetric and len(sg.dirs) == 2           # PyG's association: M^T gets its own operators
+        if r == 0:
+            own = torch.cat([p.owned(q)[p.owned(q) >= 0] for q in range(W)])
+            assert own.numel() == N and bool((torch.sort(own).values == torch.arange(N, device=cuda)).all())
+        for k, d in enumerate(sg.dirs):
+            _assert_op_equals(d.A, _expected_local_csr(sg, tgt, src, nw, "A", transpose=bool(k)))
+            _assert_op_equals(d.B, _expected_local_csr(sg, tgt, src, nw, "B", transpose=bool(k)))
+        A, B = sg.ops[0]
+        nnz[r] = A.nnz + B.nnz
+        # operands in the rank's layout: gathered hub block [W * hp] (padding rows zero), own regular rows [rp]
+        node_of_hub_row = torch.full((W * hp,), -1, dtype=torch.int64, device=cuda)
+        hub_ids = torch.nonzero(p.hub_mask).flatten()
+        node_of_hub_row[p.hub_col[hub_ids]] = hub_ids
+        xh = torch.zeros(W * hp, F, device=cuda)
+        xh[node_of_hub_row >= 0] = x[node_of_hub_row[node_of_hub_row >= 0]]
+        own_reg = sg.owned[hp:]
+        xr = torch.zeros(rp_, F, device=cuda)
+        xr[own_reg >= 0] = x[own_reg[own_reg >= 0]]
+        yB = B.spmm(xh, bias, x2=xr).cpu()
+        yA = A.spmm(xr).cpu()
+        # (1) document rows of B_r: the oracle's WHOLE row (a document's entries are words and its own loop)
+        docs = own_reg[own_reg >= 0].cpu()
+        want = csr_oracle.csr_spmm(*_rows_of_csr(rp_ref, col_ref, val_ref, docs), x_cpu, bias.cpu(), acc64=True)
+        got = yB[hp:][(own_reg >= 0).cpu()]
+        assert rel_err(got, want) < TOL and row_rel_err(got, want) < TOL, (r, rel_err(got, want), row_rel_err(got, want))
+        # (2) hub rows of B_r: the oracle's row restricted to hub (word) columns
+        own_hub = sg.owned[:hp]
+        words = own_hub[own_hub >= 0].cpu()
+        is_word = torch.arange(N) < V
+        want = csr_oracle.csr_spmm(*_rows_of_csr(rp_ref, col_ref, val_ref, words, keep_col=is_word), x_cpu, bias.cpu(),
+                                   acc64=True)
+        got = yB[:hp][(own_hub >= 0).cpu()]
+        assert rel_err(got, want) < TOL and row_rel_err(got, want) < TOL, (r, rel_err(got, want), row_rel_err(got, want))
+        # (3) A_r: every hub row restricted to the documents this rank owns
+        mine = (~is_word) & (p.owner.cpu() == r)
+        all_words = node_of_hub_row[node_of_hub_row >= 0].cpu()
+        want = csr_oracle.csr_spmm(*_rows_of_csr(rp_ref, col_ref, val_ref, all_words, keep_col=mine), x_cpu, None,
+                                   acc64=True)
+        got = yA[(node_of_hub_row >= 0).cpu()]
+        assert rel_err(got, want) < TOL and row_rel_err(got, want) < TOL, (r, rel_err(got, want), row_rel_err(got, want))
+        for d in sg.dirs:
+            d.A.close(), d.B.close()
+        del sg, xh, xr, yA, yB
+    assert abs(nnz[0] - nnz[W - 1]) <= 0.02 * max(nnz.values()), nnz
+    _report("c4_partition_8_ranks", nnz_rank0=nnz[0], nnz_rank7=nnz[W - 1])
+    del tgt, src, nw
+    # default mode: the weights of the partition are the single-device plan's, bit for bit (one degree routine)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    prp, pcol, pval = plan.export_csr()
+    ptgt = torch.repeat_interleave(torch.arange(N, device=cuda), (prp[1:] - prp[:-1]).long())
+    sg = ShardedGraph.for_rank(g.edge_index, g.edge_attr, N, W, 0, hubs=hubs)
+    assert sg.symmetric and len(sg.dirs) == 1
+    _assert_op_equals(sg.dirs[0].A, _expected_local_csr(sg, ptgt, pcol.long(), pval, "A"))
+    _assert_op_equals(sg.dirs[0].B, _expected_local_csr(sg, ptgt, pcol.long(), pval, "B"))
+
+
+def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5case):
+    """c5 (8 M nodes, 200 M edges, power law, h = 256; BASELINE.json configs[4]) over 8 ranks with `hubs=None`: every
+    node is a hub, A_r is empty, B_r = own rows x all nodes, and the exchange is the halo form.  Rank 7 in the
+    reference-order mode: both directions' operators equal the oracle's entries bit for bit; all its rows of M @ X at
+    the class width against the C CSR oracle on the oracle's rows; sampled rows at h = 256.  Its halo lists against a
+    recomputation from the edge list: the referenced columns (counts per owner, none twice, every column the operator
+    holds) and the slots it is asked for.  Rank 0 in the default mode with the symmetry fingerprint at size, weights
+    bit for bit the single-device plan's."""
+    N, W = c5case.N, 8
+    g = c5case.g
+    ei = g.edge_index
+    tgt, src, nw = c5case.oracle_coo()                      # host: 208 M entries
+    r = W - 1
+    sg = ShardedGraph.for_rank(ei, g.edge_attr, N, W, r, hubs=None, degree_sum="reference", halo_lists=True)
+    p, hp = sg.part, sg.hp
+    assert sg.rp == 0 and hp == N // W and all(d.A is None for d in sg.dirs) and len(sg.dirs) == 2
+    own_cpu = p.owner.cpu()
+    mine = own_cpu[tgt] == r
+    t_d, s_d, w_d = tgt[mine].to(cuda), src[mine].to(cuda), nw[mine].to(cuda)
+    _assert_op_equals(sg.dirs[0].B, _expected_local_csr(sg, t_d, s_d, w_d, "B"))
+    mine_t = own_cpu[src] == r
+    _assert_op_equals(sg.dirs[1].B, _expected_local_csr(sg, tgt[mine_t].to(cuda), src[mine_t].to(cuda), nw[mine_t].to(cuda),
+                                                        "B", transpose=True))
+    # halo lists, recomputed from the edge list on the host (tools/sim_halo_rows.py's logic)
+    d = sg.dirs[0]
+    hub_col = p.hub_col.cpu()
+    ei_cpu = ei.cpu()
+    e_s, e_t = ei_cpu[0], ei_cpu[1]
+    ref_need = torch.unique(torch.cat([hub_col[e_s[own_cpu[e_t] == r]], hub_col[torch.nonzero(own_cpu == r).flatten()]]))
+    need = d.need_cols.cpu()
+    assert torch.equal(need, ref_need)                                       # sorted, none twice
+    assert d.need_counts_l == torch.bincount(ref_need // hp, minlength=W).tolist()
+    _, bcol, _ = d.B.export_csr()
+    assert bool(torch.isin(torch.unique(bcol.long()).cpu(), need).all())     # every column the operator holds arrives
+    foreign = int(need.numel()) - d.need_counts_l[r]
+    _report("c5_halo_rows_rank7", referenced_rows_of_other_ranks=foreign, of=(W - 1) * hp)
+    assert 0.3 < foreign / ((W - 1) * hp) < 0.7                              # about half of the operand travels
+    # the slots this rank is asked for: peers q whose rows reference its nodes (plus its own loops)
+    slot_cpu = p.slot.cpu()
+    to_me = own_cpu[e_s] == r
+    asked = torch.unique(own_cpu[e_t[to_me]] * hp + slot_cpu[e_s[to_me]])
+    asked = torch.unique(torch.cat([asked, r * hp + slot_cpu[own_cpu == r]]))
+    assert torch.equal(d.send_slots.cpu(), asked % hp)
+    assert d.send_counts_l == torch.bincount(asked // hp, minlength=W).tolist()
+    del ei_cpu, e_s, e_t, to_me, asked
+    # rows of M @ X: the class width over ALL rows of the rank against the oracle's rows, h = 256 on sampled rows
+    rp_l, col_l, val_l = (t.cpu() for t in _expected_local_csr(sg, t_d, s_d, w_d, "B"))
+    gen = torch.Generator(device=cuda).manual_seed(31)
+    node_of_row = torch.full((W * hp,), -1, dtype=torch.int64, device=cuda)
+    node_of_row[p.hub_col] = torch.arange(N, device=cuda)
+    for F in (64, 256):
+        x = torch.randn(N, F, device=cuda, generator=gen)
+        xg = torch.zeros(W * hp, F, device=cuda)
+        xg[node_of_row >= 0] = x[node_of_row[node_of_row >= 0]]
+        y = d.B.spmm(xg)
+        if F == 64:
+            want = csr_oracle.csr_spmm(rp_l, col_l.to(torch.int32), val_l, xg.cpu(), acc64=True)
+            assert rel_err(y, want) < TOL and row_rel_err(y, want) < TOL, (rel_err(y, want), row_rel_err(y, want))
+        else:
+            deg = rp_l[1:] - rp_l[:-1]
+            rows = torch.cat([deg.topk(6).indices, torch.randint(0, hp, (120,), generator=torch.Generator().manual_seed(3))])
+            for i in rows.tolist():
+                s, e = int(rp_l[i]), int(rp_l[i + 1])
+                want = (val_l[s:e].double().unsqueeze(1) * xg[col_l[s:e].to(cuda)].double().cpu()).sum(0)
+                assert rel_err(y[i], want.float()) < TOL, i
+        del x, xg, y
+    for dd in sg.dirs:
+        dd.B.close()
+    del sg, t_d, s_d, w_d, tgt, src, nw
+    # default mode, rank 0: symmetry decided by the fingerprint at size; weights = the single-device plan's bits
+    sg = ShardedGraph.for_rank(ei, g.edge_attr, N, W, 0, hubs=None)
+    assert sg.symmetric and len(sg.dirs) == 1
+    plan = GraphPlan(ei, g.edge_attr, N)
+    prp, pcol, pval = plan.export_csr()
+    lo_hi = torch.nonzero(sg.part.owner == 0).flatten()
+    ptgt = torch.repeat_interleave(torch.arange(N, device=cuda), (prp[1:] - prp[:-1]).long())
+    keep = sg.part.owner[ptgt] == 0
+    _assert_op_equals(sg.dirs[0].B, _expected_local_csr(sg, ptgt[keep], pcol[keep].long(), pval[keep], "B"))
+    assert int(keep.sum()) == sg.dirs[0].B.nnz and lo_hi.numel() == N // W

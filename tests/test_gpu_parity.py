@@ -99,10 +99,13 @@ def test_known_answer_vector(cuda):
     (4, 400, 1500, 6, 5, True, False, True), (5, 640, 400, 0, 0, True, False, True),
     (6, 500, 3000, 5, 5, True, True, False), (7, 500, 3000, 5, 5, False, False, False),
 ])
-def test_plan_matches_gcn_norm(cuda, seed, n, e, loops, dups, weighted, add_loops, normalize):
+@pytest.mark.parametrize("degree_sum", ["accurate", "reference"])
+def test_plan_matches_gcn_norm(cuda, seed, n, e, loops, dups, weighted, add_loops, normalize, degree_sum):
+    """`degree_sum="reference"` (PyG's sequential fp32 degree sums and its association): the weights must be the
+    oracle's BIT FOR BIT; the default (float64 sums, symmetric association) within 2e-6."""
     g = synth.random_graph(n, e, seed=seed, self_loops=loops, duplicates=dups, weighted=weighted)
     ei, w = g.edge_index, g.edge_attr
-    plan = GraphPlan(ei.to(cuda), None if w is None else w.to(cuda), n, add_loops, normalize)
+    plan = GraphPlan(ei.to(cuda), None if w is None else w.to(cuda), n, add_loops, normalize, degree_sum=degree_sum)
     if normalize:
         tgt, src, nw = O.normalized_coo(ei, w, n, add_loops)
     else:
@@ -118,11 +121,14 @@ def test_plan_matches_gcn_norm(cuda, seed, n, e, loops, dups, weighted, add_loop
         assert torch.equal(rp.cpu().long(), rp_ref)
         assert torch.equal(col.cpu().long(), b[order])
         assert rel_err(val, nw[order]) < 2e-6
+        if degree_sum == "reference" or not normalize:
+            assert torch.equal(val.cpu().view(torch.int32), nw[order].float().view(torch.int32))
     assert plan.symmetric is False or e == 0
 
 
+@pytest.mark.parametrize("degree_sum", ["accurate", "reference"])
 @pytest.mark.parametrize("add_loops,chunk", [(1, None), (1, "1024"), (2, "1500"), (0, "1024")])
-def test_gcn_norm_entry_point_matches_the_oracle(cuda, monkeypatch, add_loops, chunk):
+def test_gcn_norm_entry_point_matches_the_oracle(cuda, monkeypatch, add_loops, chunk, degree_sum):
     """tgcn_gcn_norm (the normalisation half of the plan on its own, used by the 1-D partition): deg^-1/2 and
     the loop weight per node against the oracle's add_remaining_self_loops + degree sum, with the edge list
     walked in one chunk and in many (TGCN_NORM_CHUNK), loops of weight 1 / 2 (improved) / none, and the
@@ -141,12 +147,36 @@ def test_gcn_norm_entry_point_matches_the_oracle(cuda, monkeypatch, add_loops, c
     dis_ref = deg.pow(-0.5)
     dis_ref[torch.isinf(dis_ref)] = 0
     ei_view = ei.t().contiguous().to(cuda).t()                   # [2, E] view with strides (1, 2)
-    dis, loop_w = HipEngine().gcn_norm(ei_view, w.to(cuda), 3000, add_loops)
+    dis, loop_w = HipEngine().gcn_norm(ei_view, w.to(cuda), 3000, add_loops, degree_sum)
     assert torch.equal(loop_w.cpu(), loop_ref)
     assert rel_err(dis, dis_ref.float()) < 1e-6
+    if degree_sum == "reference":
+        # the oracle's own fp32 factors (sequential index_add_ in edge order, the loop last; deg.pow(-0.5)), bit for
+        # bit, however the edge list is chunked
+        d32 = torch.zeros(3000).index_add_(0, ei2[1], w2).pow(-0.5)
+        d32[d32 == float("inf")] = 0
+        assert torch.equal(dis.cpu().view(torch.int32), d32.view(torch.int32))
+    else:
+        # the float64 sum rounded once: the correctly rounded degree, whatever the chunking
+        d64 = deg.float().pow(-0.5)
+        d64[d64 == float("inf")] = 0
+        assert torch.equal(dis.cpu().view(torch.int32), d64.view(torch.int32))
+    # it is the routine the plan itself runs: the plan's weights are w * (dis[s] * dis[t]) of THESE factors, bit for bit
+    plan = GraphPlan(ei_view, w.to(cuda), 3000, add_loops, True, degree_sum=degree_sum)
+    rp, col, val = plan.export_csr()
+    rows = torch.repeat_interleave(torch.arange(3000, device=cuda), (rp[1:] - rp[:-1]).long())
+    keep = ei[0] != ei[1] if add_loops else torch.ones(ei.size(1), dtype=torch.bool)
+    s_e, t_e, w_e = ei[0][keep].to(cuda), ei[1][keep].to(cuda), w[keep].to(cuda)
+    if add_loops:
+        ar = torch.arange(3000, device=cuda)
+        s_e, t_e, w_e = torch.cat([s_e, ar]), torch.cat([t_e, ar]), torch.cat([w_e, loop_w])
+    want = (dis[s_e] * w_e) * dis[t_e] if degree_sum == "reference" else w_e * (dis[s_e] * dis[t_e])
+    order = torch.argsort(t_e * 3000 + s_e, stable=True)
+    assert torch.equal(rows, t_e[order]) and torch.equal(col.long(), s_e[order])
+    assert torch.equal(val.view(torch.int32), want[order].view(torch.int32))
     # isolated node: degree 0 -> inf -> 0 (masked_fill), with and without its loop
     ei3 = torch.tensor([[0, 1], [1, 0]])
-    d3, l3 = HipEngine().gcn_norm(ei3.to(cuda), None, 3, add_loops)
+    d3, l3 = HipEngine().gcn_norm(ei3.to(cuda), None, 3, add_loops, degree_sum)
     want = {1: [2 ** -0.5, 2 ** -0.5, 1.0], 2: [3 ** -0.5, 3 ** -0.5, 2 ** -0.5], 0: [1.0, 1.0, 0.0]}[add_loops]
     assert torch.allclose(d3.cpu(), torch.tensor(want), atol=1e-6)
     assert l3.cpu().tolist() == [float(add_loops)] * 3
@@ -484,8 +514,36 @@ def test_row_movement_kernels_of_the_exchange(cuda, F):
     eng.reduce_ranked_(yh, recv, inv.to(cuda), W, n, k, K)
     assert torch.equal(yh, want)
     lib = _lib.load()
-    assert lib.tgcn_rows_gather(x.data_ptr(), F - 1, idx.data_ptr(), 3, F, y.data_ptr(), F, None) == _lib.E_INVALID
-    assert lib.tgcn_rows_reduce_ranked(None, F, inv.to(cuda).data_ptr(), 0, n, F, yh.data_ptr(), F, 0, 1, None) == _lib.E_INVALID
+    assert lib.tgcn_rows_gather(x.data_ptr(), F - 1, 5000, idx.data_ptr(), 3, F, y.data_ptr(), F, None) == _lib.E_INVALID
+    inv_d = inv.to(cuda)
+    assert lib.tgcn_rows_reduce_ranked(None, F, 0, inv_d.data_ptr(), 0, n, F, yh.data_ptr(), F, yh.size(0), 0, 1,
+                                       None) == _lib.E_INVALID
+    # the target rows k + j * K must lie inside y: refused before anything is enqueued
+    assert lib.tgcn_rows_reduce_ranked(recv.data_ptr(), F, recv.size(0), inv_d.data_ptr(), W, n, F, yh.data_ptr(), F,
+                                       n * K - 5, k, K, None) == _lib.E_RANGE
+    # an index outside the row count a call is given is SKIPPED on the device -- a bad list never touches memory
+    # outside the buffers (the calls only enqueue and cannot report it)
+    bad = idx.clone()
+    bad[5], bad[9] = 5000, -3
+    got = torch.full((1777, F), 7.0, device=cuda)
+    _lib.check(lib.tgcn_rows_gather(x.data_ptr(), F, 5000, bad.data_ptr(), 1777, F, got.data_ptr(), F, None))
+    ok = torch.ones(1777, dtype=torch.bool, device=cuda)
+    ok[5] = ok[9] = False
+    assert torch.equal(got[ok], x.index_select(0, idx)[ok]) and bool((got[~ok] == 7).all())
+    y2 = torch.zeros(6000, F, device=cuda)
+    bad[5], bad[9] = 6000, 1 << 40
+    _lib.check(lib.tgcn_rows_scatter(rows.data_ptr(), F, bad.data_ptr(), 1777, F, y2.data_ptr(), F, 6000, None))
+    ref2 = torch.zeros(6000, F, device=cuda).index_copy_(0, idx[ok], rows[ok])
+    assert torch.equal(y2, ref2)
+    # the Python wrappers refuse what the raw pointers cannot express
+    with pytest.raises(TypeError):
+        eng.rows_gather(x, idx.int())
+    with pytest.raises(TypeError):
+        eng.rows_gather(x.double(), idx)
+    with pytest.raises(TypeError):
+        eng.rows_gather(x, idx.cpu())
+    with pytest.raises(TypeError):
+        eng.reduce_ranked_(yh, recv, inv_d.long(), W, n, k, K)
 
 
 def test_synthetic_graphs_do_not_depend_on_the_device_they_are_built_on(cuda):
@@ -556,22 +614,6 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
         ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
         assert rel_err(mx[r], ref.float()) < TOL, r          # one row: this IS the row-relative error
     del rows, rowsum
-
-
-def _oracle_csr(ei, w, N, rows=None):
-    """The ORACLE's normalisation (oracle/gcn_oracle.py: add_remaining_self_loops + gcn_norm, the PyG-1.6.3
-    algorithm the reference runs at textgcn/lib/models.py:11-20) as CSR with the entries of a row sorted by
-    column, ties in edge order -- the order the plan documents.  `rows=(lo, hi)` keeps the target rows
-    [lo, hi) only (the degrees still come from every edge)."""
-    tgt, src, nw = O.normalized_coo(ei.cpu(), None if w is None else w.cpu(), N)
-    lo, hi = (0, N) if rows is None else rows
-    if rows is not None:
-        keep = (tgt >= lo) & (tgt < hi)
-        tgt, src, nw = tgt[keep], src[keep], nw[keep]
-    order = torch.argsort(tgt * N + src, stable=True)
-    rp = torch.zeros(hi - lo + 1, dtype=torch.int64)
-    rp[1:] = torch.bincount(tgt - lo, minlength=hi - lo).cumsum(0)
-    return rp, src[order].to(torch.int32), nw[order]
 
 
 def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=None, case=None):
@@ -688,19 +730,19 @@ def test_config_c4_w1_update_in_the_backward_spmm_is_bitwise_at_full_size(cuda):
     assert oa.state[wa]["step"] == ob.state[wb]["step"] == 2
 
 
-def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda):
+def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda, c4case):
     """The c4 plan (50 M edges) against the oracle's OWN normalisation, not against itself: rowptr / col
     bit-exact, values to 2e-6; then rows [0, 60 000) of M @ X (all word rows up to 1.3 M non-zeros each,
     ~10 M non-zeros) against the C CSR oracle run on the ORACLE's CSR."""
     N, E, F = 2_000_000, 50_000_000, 200
-    g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
+    g = c4case.g
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
     assert plan.stats()["hot_rows"] > 0                         # the benchmark configuration of the kernels
-    rp_ref, col_ref, val_ref = _oracle_csr(g.edge_index, g.edge_attr, N)
+    rp_ref, col_ref, val_ref, order = c4case.oracle_csr()
     rp, col, val = plan.export_csr()
     # which side of the heavy-row discrepancy is off: both against float64 (degrees summed in float64 on the host)
-    tgt, src, w64 = _truth_normalized_coo(g.edge_index, g.edge_attr, N)
-    order = torch.argsort(tgt * N + src, stable=True)
+    tgt, src, _ = c4case.oracle_coo()
+    w64 = c4case.truth_w64()
     val64 = w64[order]                                          # the float64 weights in CSR order
     _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=val64, case="c4_weights")
     del rp, col, val, order
@@ -1308,12 +1350,12 @@ def test_config_c3_dbpedia_shaped_graph(cuda):
     _sampled_row_check(plan, x, out - b, rows)
 
 
-def test_config_c5_power_law_graph_h256(cuda):
+def test_config_c5_power_law_graph_h256(cuda, c5case):
     """8 M nodes / 200 M edges, degree ~ power law, h = 256 (BASELINE.json configs[4]); no hub/regular
     structure.  A row block and the heaviest rows are checked against the ORACLE's normalisation and the C
     CSR oracle; the whole result through size-independent properties and sampled rows."""
     N, E, F = 8_000_000, 200_000_000, 256
-    g = synth.power_law_graph(N, E, seed=44, device=cuda)
+    g = c5case.g
     assert g.edge_index.shape == (2, E)
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
     assert plan.symmetric and plan.nnz == E + N
@@ -1326,11 +1368,8 @@ def test_config_c5_power_law_graph_h256(cuda):
     assert plan.stats()["long_rows"] > 0
     # oracle normalisation of the target rows [0, R) and of the six heaviest rows
     R = 150_000
-    ei_cpu, w_cpu = g.edge_index.cpu(), g.edge_attr.cpu()
-    del g
-    tgt, src, nw = O.normalized_coo(ei_cpu, w_cpu, N)
-    _, _, w64 = _truth_normalized_coo(ei_cpu, w_cpu, N)          # same (edges, loops) order as the oracle's
-    del ei_cpu, w_cpu
+    tgt, src, nw = c5case.oracle_coo()
+    w64 = c5case.truth_w64()                                     # same (edges, loops) order as the oracle's
     heavy = deg.topk(8).indices.cpu()
     pick = (tgt < R) | torch.isin(tgt, heavy)
     tgt, src, nw, w64 = tgt[pick], src[pick], nw[pick], w64[pick]
