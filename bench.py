@@ -35,6 +35,7 @@ CONFIGS = {
     "c5": (8_000_000, 200_000_000, 256, 64),     # generic power law (no word / document structure), h = 256
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+FABRIC_GATHER_CEILING_GBPS = 8600.0   # MI355X_MICROARCH.md 'Indexed rows': random rows of an Infinity-Cache-resident table
 
 
 def parse():
@@ -46,44 +47,106 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
     p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 32)
+    p.add_argument("--cpu-ref", choices=["auto", "full", "sample"], default="auto",
+                   help="CPU-ref baseline on the full operator (needs ~100 GB of host memory at c4), on a row sample, "
+                        "or full when MemAvailable allows it (default)")
     p.add_argument("--no-hbm-activity", action="store_true", help="skip the live memory-controller measurement")
     p.add_argument("--launch-check", action="store_true",
                    help="rendezvous only: every rank joins the group, rank 0 prints {launch_check, n_gpus}; no GPU work")
     return p.parse_args()
 
 
-def launch_ranks(args) -> int:
-    """`python3 bench.py --gpus N` (N > 1) without a rendezvous environment: start one rank per GPU as a CHILD
-    `python -m torch.distributed.run` (never an exec, and before this process has made any GPU call), relay the one
-    JSON line rank 0 prints and hand back the child's return code.  Under torch.distributed.run (WORLD_SIZE set) this
-    function is not reached."""
-    import socket
+def _run_ranks(cmd, env, budget_s):
+    """One child `torch.distributed.run` in its own session (so that the whole tree -- launcher and ranks -- can be ended
+    by its process-group id, the exact group started here).  Returns (return code or None on timeout, stdout text)."""
+    import signal
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)       # stderr passes straight through
+    import tempfile
+    with tempfile.TemporaryFile() as out:
+        proc = subprocess.Popen(cmd, stdout=out, env=env, start_new_session=True)      # stderr passes straight through
+        try:
+            rc = proc.wait(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            rc = None
+        if rc is None or rc != 0:
+            # over budget, or a rank died while its peers may still sit in a collective: end the group we started
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    break
+                try:
+                    proc.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+        out.seek(0)
+        return rc, out.read().decode("utf-8", "replace")
+
+
+def _last_record(text):
     record = None
-    for ln in res.stdout.decode("utf-8", "replace").splitlines():
+    for ln in text.splitlines():
         ln = ln.strip()
         if ln.startswith("{") and ln.endswith("}"):
             try:
-                json.loads(ln)
-                record = ln
+                record = json.loads(ln)
             except ValueError:
                 pass
-    if record is not None:
-        print(record, flush=True)
-    elif res.returncode == 0:
-        print("bench.py: the ranks exited cleanly but printed no record", file=sys.stderr)
-        return 1
-    return res.returncode
+    return record
+
+
+def launch_ranks(args) -> int:
+    """`python3 bench.py --gpus N` (N > 1) without a rendezvous environment: start one rank per GPU as a CHILD
+    `python -m torch.distributed.run` (never an exec, and before this process has made any GPU call -- it never
+    makes one), relay the one JSON line rank 0 prints and hand back the child's return code.
+
+    The measurement must not be lost to a form of the exchange that hangs or dies on this node: the child gets a wall
+    budget (TGCN_BENCH_BUDGET_S, default 420 s).  If it exceeds it, exits non-zero or prints no record, its process group
+    is ended and a FRESH child runs the plainest configuration -- RCCL's own collectives, A_r in one piece, no trial
+    steps, no epoch (TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch; budget TGCN_BENCH_FALLBACK_BUDGET_S, default
+    300 s) -- and its record is relayed with a `"fallback"` field saying why.  Under torch.distributed.run (WORLD_SIZE
+    set) this function is not reached."""
+    import socket
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    def command(extra):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] \
+            + sys.argv[1:] + extra
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    budget = float(os.environ.get("TGCN_BENCH_BUDGET_S", "420"))
+    t0 = time.time()
+    rc, text = _run_ranks(command([]), env, budget)
+    record = _last_record(text)
+    if rc == 0 and record is not None:
+        print(json.dumps(record), flush=True)
+        return 0
+    reason = (f"first attempt exceeded its budget of {budget:.0f} s" if rc is None else
+              f"first attempt exited with code {rc}" if rc != 0 else "first attempt printed no record")
+    print(f"bench.py: {reason} after {time.time() - t0:.0f} s; running the plain configuration "
+          "(TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch)", file=sys.stderr, flush=True)
+    if os.environ.get("TGCN_BENCH_NO_FALLBACK") == "1":
+        return rc if rc else 1
+    env2 = dict(env, TGCN_EXCHANGE="collective", TGCN_RS_CHUNKS="1")
+    env2.pop("TGCN_BENCH_TEST_FAIL", None)               # (the test hook below applies to the first attempt only)
+    rc2, text2 = _run_ranks(command([] if "--no-epoch" in sys.argv else ["--no-epoch"]), env2,
+                            float(os.environ.get("TGCN_BENCH_FALLBACK_BUDGET_S", "300")))
+    record = _last_record(text2)
+    if rc2 == 0 and record is not None:
+        record["fallback"] = reason
+        print(json.dumps(record), flush=True)
+        return 0
+    print(f"bench.py: the fallback run failed too (return code {rc2})", file=sys.stderr, flush=True)
+    return rc2 if rc2 else 1
 
 
 def launch_check(world, rank):
@@ -91,6 +154,12 @@ def launch_check(world, rank):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
+    # test hook of the fallback path (tests/test_host.py): the last rank of the FIRST attempt dies or hangs
+    fail = os.environ.get("TGCN_BENCH_TEST_FAIL")
+    if fail and rank == world - 1:
+        if fail == "exit":
+            os._exit(1)
+        time.sleep(3600)
     t = torch.tensor([float(rank)])
     dist.all_reduce(t)
     ok = t.item() == world * (world - 1) / 2
@@ -99,6 +168,38 @@ def launch_check(world, rank):
     if rank == 0:
         print(json.dumps({"launch_check": bool(ok), "n_gpus": world}), flush=True)
     return 0 if ok else 1
+
+
+def init_group(dist, backend, dev, **kw):
+    """The process group of the bench: pytextgcn_amd.sharded.init_process_group (RCCL on a HIGH-PRIORITY stream, so that
+    the exchange is scheduled while the SpMM grids fill the CUs) with a bound on every collective -- one that does not
+    complete within TGCN_BENCH_COLLECTIVE_TIMEOUT_S (default 180 s; a rank died, a form of the exchange hung) ends the
+    process instead of waiting for ever, so that the parent (launch_ranks) can run its fallback."""
+    from pytextgcn_amd.sharded import init_process_group
+    init_process_group(backend, dev, timeout_s=float(os.environ.get("TGCN_BENCH_COLLECTIVE_TIMEOUT_S", "180")), **kw)
+
+
+def rccl_info(dist, backend, world, rank, local_rank, dev):
+    """Who took part: per rank the device index, its name, PCI bus id and UUID -- so that a reader of the record can
+    tell N GPUs from N ranks on fewer (rehearsals put every gloo rank on one card)."""
+    pr = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device": dev.index, "name": pr.name,
+            "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                              getattr(pr, "pci_device_id", 0)),
+            "uuid": str(getattr(pr, "uuid", ""))}
+    info = [mine]
+    if dist is not None and world > 1:
+        info = [None] * world
+        dist.all_gather_object(info, mine)
+    hi = None
+    if dist is not None and backend == "nccl":
+        try:
+            hi = bool(dist.distributed_c10d._get_default_group()._get_backend(dev).options.is_high_priority_stream)
+        except Exception:                   # noqa: BLE001 - introspection only
+            hi = None
+    return {"backend": {"nccl": "nccl (RCCL)"}.get(backend, backend) if dist is not None else None, "ranks": world,
+            "distinct_devices": len({(d["pci_bus_id"], d["uuid"]) for d in info}),
+            "high_priority_stream": hi, "devices": info}
 
 
 def cpu_model():
@@ -112,37 +213,69 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5):
-    """The two CPU rows of BASELINE.md section 3, on this box's host cores, same graph / seed / fp32,
-    `warm` warm-up + `reps` timed repetitions each, median:
+def mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 1e6           # kB -> GB
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
+def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5, full="auto", ref_budget_s=150.0):
+    """The two CPU rows of BASELINE.md section 3, on this box's host cores, same graph / seed / fp32, median of the timed
+    repetitions:
       CPU-ref (`value`)  the reference formulation (PyG-1.6.3 index_select -> scale -> scatter_add,
-                         oracle/gcn_oracle.py `propagate`) over the sub-operator whose TARGET rows are a random
-                         `frac` of the nodes (forward) and its transpose (backward): a bounded sample, because
-                         the formulation materialises two nnz x F temporaries (41.6 GB each at full c4);
+                         oracle/gcn_oracle.py `propagate`), forward and transposed.  It materialises two nnz x F
+                         temporaries (41.6 GB each at c4), so: when the host has the memory (MemAvailable >= 200 GB, or
+                         `full=True`) it runs on the FULL operator -- the same workload the GPU is timed on -- with 1
+                         warm-up pair and up to 3 timed pairs inside `ref_budget_s` seconds (at least one); otherwise
+                         on the sub-operator whose TARGET rows are a random `frac` of the nodes (3 + 5 repetitions),
+                         and `sample` says which and why;
       CPU-csr (`csr`)    the C / OpenMP CSR restatement (oracle/csr_spmm.c, `oracle_csr_spmm_f32`) of M @ X and
-                         M^T @ G on the FULL operator."""
+                         M^T @ G on the FULL operator, `warm` + `reps` repetitions."""
     from oracle import csr_oracle, gcn_oracle as O
     N = plan.num_nodes
     gen = torch.Generator().manual_seed(seed)
     rp, col, val = (t.cpu() for t in plan.export_csr())
-    pick = torch.rand(N, generator=gen) < frac
     deg = (rp[1:] - rp[:-1]).long()
     rows = torch.repeat_interleave(torch.arange(N), deg)
-    sel = pick[rows]
-    tgt, src, w = rows[sel], col[sel].long(), val[sel]
-    del rows, sel
+    avail = mem_available_gb()
+    need_gb = 2.2 * float(plan.nnz) * F * 4 / 1e9 + 20.0          # two nnz x F temporaries + operands, with margin
+    run_full = (full is True) or (full == "auto" and avail is not None and avail >= max(200.0, 1.5 * need_gb))
+    if run_full:
+        tgt, src, w = rows, col.long(), val
+        why = (f"the FULL operator (MemAvailable {avail:.0f} GB >= the {need_gb:.0f} GB the two nnz x F temporaries need)"
+               if avail is not None else "the FULL operator")
+        warm_ref, reps_ref = 1, 3
+    else:
+        pick = torch.rand(N, generator=gen) < frac
+        sel = pick[rows]
+        tgt, src, w = rows[sel], col[sel].long(), val[sel]
+        del sel
+        why = (f"the rows of a random {frac:.4f} of the nodes of the same graph (MemAvailable "
+               f"{'unknown' if avail is None else '%.0f GB' % avail} < the {max(200.0, 1.5 * need_gb):.0f} GB bound for the full "
+               f"operator: it materialises two nnz x F temporaries)")
+        warm_ref, reps_ref = warm, reps
+    del rows
     n_edges = int((tgt != src).sum())                       # self-loops are not graph edges
     x = torch.randn(N, F, generator=gen)
     fwd = torch.stack([src, tgt])                           # out[tgt] += w * x[src]
     bwd = torch.stack([tgt, src])                           # dxw[src] += w * g[tgt]
     times = []
-    for rep in range(warm + reps):
+    t_leg = time.perf_counter()
+    for rep in range(warm_ref + reps_ref):
         t0 = time.perf_counter()
         O.propagate(fwd, x, w, N)
         O.propagate(bwd, x, w, N)
-        if rep >= warm:
+        if rep >= warm_ref:
             times.append(time.perf_counter() - t0)
+            if run_full and time.perf_counter() - t_leg > ref_budget_s:
+                break
     t_ref = sorted(times)[len(times) // 2]
+    n_ref_reps = len(times)
     n_sel = int(w.numel())
     del fwd, bwd, tgt, src, w
     # CPU-csr at full size (the operator is symmetric here; otherwise the transposed CSR is exported)
@@ -168,11 +301,11 @@ def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5):
     t_csr = sorted(times)[len(times) // 2]
     threads = torch.get_num_threads()
     return {"value": 2.0 * n_edges / t_ref, "unit": "edges/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
-            "sample": f"CPU-ref: reference formulation (gather->scale->index_add, fwd+bwd) on the rows of a "
-                      f"random {frac:.4f} of the nodes of the same graph: {n_edges} edges, {n_sel} non-zeros, "
-                      f"F={F}, {warm} warm-up + {reps} timed reps, median {t_ref:.2f} s per fwd+bwd pair, "
-                      f"torch threads {threads}",
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "full_operator": bool(run_full),
+            "mem_available_GB": avail,
+            "sample": f"CPU-ref: reference formulation (gather->scale->index_add, fwd+bwd) on {why}: {n_edges} edges, "
+                      f"{n_sel} non-zeros, F={F}, {warm_ref} warm-up + {n_ref_reps} timed reps, median {t_ref:.2f} s per "
+                      f"fwd+bwd pair, torch threads {threads}",
             "csr": {"value": 2.0 * E / t_csr, "unit": "edges/s", "kind": "port",
                     "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
                     "sample": f"CPU-csr: oracle_csr_spmm_f32 (C, OpenMP) M@X and M^T@G on the FULL operator, "
@@ -491,15 +624,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        init_group(dist, backend, dev)
 
     from pytextgcn_amd import synth
     from pytextgcn_amd.plan import GraphPlan
 
     N, E, F, C = CONFIGS[args.config]
+    setup_s = {}                       # wall time of the one-off construction steps (not part of the metric)
+    t_setup = time.perf_counter()
     gen_kw = dict(vocab_frac=0.03, doc_word_share=0.9) if args.config == "c3" else {}
 
     def make_graph(features):
@@ -523,6 +655,9 @@ def main():
         for t in (coo, attr, meta):
             dist.broadcast(t, src=0)
         g = Data(x=None, edge_index=coo.t(), edge_attr=attr, n_vocab=int(meta.item()))
+    torch.cuda.synchronize()
+    setup_s["graph_generation" + ("_and_broadcast" if world > 1 else "")] = round(time.perf_counter() - t_setup, 3)
+    t_setup = time.perf_counter()
     gen = torch.Generator(device=dev).manual_seed(1234)
     bias = torch.randn(F, device=dev, generator=gen)
 
@@ -552,7 +687,7 @@ def main():
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            init_group(dist, "nccl", dev, rank=0, world_size=1)
         # word nodes: replicated operand block; a graph without them (c5) has no hub structure -> every node's
         # rows may be needed anywhere: the halo exchange sends the referenced ones
         hubs = torch.arange(N, device=dev) < g.n_vocab if g.n_vocab > 0 else None
@@ -582,30 +717,43 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    setup_s["plan" if parallelism == "single" else "partition_normalisation_local_operators_index_lists"] = \
+        round(time.perf_counter() - t_setup, 3)
+    t_setup = time.perf_counter()
 
     # N > 1: the exchange of the distributed SpMM has two forms (RCCL collectives / pairwise transfers + all-to-all,
     # pytextgcn_amd.sharded); which one is faster depends on what RCCL makes of the xGMI mesh, so a few untimed
     # steps of each decide (max over ranks, the same answer on every rank).  TGCN_EXCHANGE pins the form.
     exchange_selection = None
     if world > 1 and "TGCN_EXCHANGE" not in os.environ:
-        forms = list(sg.EXCHANGES)
+        forms = list(sg.EXCHANGES)                  # "collective" first: RCCL's own collectives with A_r in one piece
         chunkings = [1, 2, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
-        trial = {}
+        trial = {}                                 # is the configuration the fallback of launch_ranks() runs, too
         for K in chunkings:
             sg.set_rs_chunks(K)
             for mode in forms:
                 sg.exchange = mode
-                try:                       # a form this backend / build refuses raises on every rank alike: skip it
+                # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
+                # skipped.  A failure on ONE rank in the middle of a step leaves its peers inside a collective: they
+                # are released by the group's timeout (init_group), the process ends, and launch_ranks() runs the
+                # plain configuration in a fresh child -- nothing here tries to outwit a broken exchange.
+                ok = 1.0
+                ms = float("inf")
+                try:
                     step()
+                except RuntimeError as e:
+                    print(f"bench.py: exchange form {mode}/{K} failed on rank {rank}: {e}"[:300], file=sys.stderr, flush=True)
+                    ok = 0.0
+                flag = torch.tensor([ok], device=dev, dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same branch
+                if flag.item() > 0:
                     barrier()
                     t0 = time.perf_counter()
                     for _ in range(3):
                         step()
                     barrier()
                     ms = (time.perf_counter() - t0) / 3 * 1e3
-                except RuntimeError as e:
-                    print(f"bench.py: exchange form {mode}/{K} failed on rank {rank}: {e}"[:300], file=sys.stderr, flush=True)
-                    ms = float("inf")
                 t = torch.tensor([ms], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[f"{mode}/{K}"] = t.item()
@@ -615,10 +763,14 @@ def main():
         trial = {k: (v if v != float("inf") else None) for k, v in trial.items()}
         sg.exchange = best.split("/")[0]
         sg.set_rs_chunks(int(best.split("/")[1]))
+        sg.drop_unused_chunks()                    # the chunk operators of the counts that lost are dead weight
         exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows()}
         parallelism = (f"row{world}: " + ("hubs(words) replicated, hub rows reduce-scattered" if sg.rp > 0 else
                                           "no hub structure: operand rows exchanged") +
                        f" (exchange form / A_r row chunks = {best}, the fastest of {trial})")
+    if exchange_selection is not None:
+        torch.cuda.synchronize()
+        setup_s["exchange_trial_steps"] = round(time.perf_counter() - t_setup, 3)
     for _ in range(args.warmup):
         step()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -661,6 +813,7 @@ def main():
         epoch_ms_w1_reuse = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True)    # both switches are bitwise neutral
         epoch_ms_split = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True)
 
+    rccl = rccl_info(dist, backend, world, rank, local_rank, dev)        # collective: every rank takes part
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -668,9 +821,9 @@ def main():
         #   algorithmic  SURVEY 8(d): every gathered row charged to HBM (no cache reuse assumed).  > peak on
         #                this path: the word block is served by L2 / Infinity Cache and the dense hot block
         #                reads X once -- it measures work done, not memory traffic;
-        #   hbm          bytes the memory controllers actually moved (live, `hbm_activity`)  -> `frac`;
+        #   hbm          bytes the memory controllers actually moved (live, `hbm_activity`);
         #   fabric       L2 <-> fabric bytes from the committed rocprofv3 PMC passes (Infinity-Cache hits
-        #                included: an upper bound on HBM bytes; the link the kernel is in fact bound by);
+        #                included: an upper bound on HBM bytes; the link the kernel is in fact bound by)  -> `frac`;
         #   compulsory   every input and output touched exactly once (lower bound).
         per_s = 1.0 / (launch_ms * 1e-3) / 1e9
         n_out = N if parallelism == "single" else sg.n_local
@@ -679,29 +832,50 @@ def main():
         hbm_bytes = None
         if hbm and "bytes_per_step" in hbm:
             hbm_bytes = hbm["bytes_per_step"] / 2.0            # a step is two launches (forward, transposed)
-        # `frac`: counter traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this bench command, committed under
-        # profiles/) when it was collected on these very kernel sources -- basis "fabric": what crosses the L2 <->
-        # Infinity Cache / HBM link, the link this kernel is bound by; otherwise the live memory-controller figure --
-        # basis "hbm".  Both are always reported side by side (frac_fabric, frac_hbm).
-        frac_fabric = None if fabric is None else fabric * per_s / HBM_PEAK_GBPS
-        frac_hbm = None if hbm_bytes is None else hbm_bytes * per_s / HBM_PEAK_GBPS
+        # THE CONTRACT OF THIS OBJECT (frozen in round 4; tests/test_host.py holds it):
+        #   achieved   GB/s that `frac` is a fraction of:  traffic / launch time;   frac = achieved / peak, raw (never
+        #              capped: a value above 1 is reported as it is, with "non_physical": true)
+        #   traffic    bytes per launch on the basis `frac_basis` names:
+        #                "fabric"  counter traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this bench command,
+        #                          committed under profiles/, collected on these very kernel sources): what crosses the
+        #                          L2 <-> Infinity Cache / HBM link -- the link this kernel is bound by.  The counters
+        #                          count Infinity-Cache hits too, so it is an UPPER bound on HBM bytes;
+        #                "hbm"     the live memory-controller figure, when no fresh counter profile is on file;
+        #                "fabric-stale" / "algorithmic"  last resorts (older kernels' counters / no measurement at all)
+        #   achieved_algorithmic / _fabric / _hbm  and  frac_algorithmic / _fabric / _hbm / _compulsory  always stand
+        #   side by side, each = its byte count / launch time (/ peak).
+        ach_alg = achieved
+        ach_fabric = None if fabric is None else fabric * per_s
+        ach_hbm = None if hbm_bytes is None else hbm_bytes * per_s
+        frac_fabric = None if ach_fabric is None else ach_fabric / HBM_PEAK_GBPS
+        frac_hbm = None if ach_hbm is None else ach_hbm / HBM_PEAK_GBPS
         if fabric is not None and fabric_fresh:
-            frac, frac_basis, traffic, traffic_basis = frac_fabric, "fabric", fabric, fabric_src
+            ach, frac_basis, traffic, traffic_basis = ach_fabric, "fabric", fabric, fabric_src
         elif hbm_bytes is not None:
-            frac, frac_basis, traffic = frac_hbm, "hbm", hbm_bytes
+            ach, frac_basis, traffic = ach_hbm, "hbm", hbm_bytes
             traffic_basis = "live: sysfs mem_busy_percent while the step loops, calibrated on a 1 GiB device copy"
         elif fabric is not None:
-            frac, frac_basis, traffic, traffic_basis = frac_fabric, "fabric-stale", fabric, fabric_src + " (older kernels)"
+            ach, frac_basis, traffic, traffic_basis = ach_fabric, "fabric-stale", fabric, fabric_src + " (older kernels)"
         else:
-            frac, frac_basis, traffic, traffic_basis = min(achieved / HBM_PEAK_GBPS, 1.0), "algorithmic-capped", None, None
+            ach, frac_basis, traffic, traffic_basis = ach_alg, "algorithmic", launch_bytes, "SURVEY 8(d) gather model, no measurement"
+        frac = ach / HBM_PEAK_GBPS
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": frac, "frac_basis": frac_basis,
+            "bound": "hbm",
+            "bound_detail": "memory-bound gather; the binding link is L2 <-> fabric (Infinity Cache + HBM behind it): "
+                            "`frac` on basis 'fabric' is counter traffic over the 8 TB/s HBM peak -- an upper bound on "
+                            "the HBM fraction, which is `frac_hbm` (memory controllers, live)",
+            "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": frac, "frac_basis": frac_basis, "non_physical": bool(frac > 1.0),
             "traffic": traffic, "traffic_basis": traffic_basis,
             "hbm_activity": hbm,
-            "frac_algorithmic": achieved / HBM_PEAK_GBPS,
+            "achieved_algorithmic": ach_alg, "achieved_fabric": ach_fabric, "achieved_hbm": ach_hbm,
+            "frac_algorithmic": ach_alg / HBM_PEAK_GBPS,
             "frac_hbm": frac_hbm,
             "frac_fabric": frac_fabric,
+            # the same counter traffic against what the guide measures for Infinity-Cache-resident row gathers
+            # (MI355X_MICROARCH.md 'Indexed rows': 8.6 TB/s chip-wide for a 38 MB table): the delivery ceiling of the link
+            "fabric_gather_ceiling_GBps": FABRIC_GATHER_CEILING_GBPS,
+            "frac_fabric_of_gather_ceiling": None if ach_fabric is None else ach_fabric / FABRIC_GATHER_CEILING_GBPS,
             "traffic_fabric": fabric, "traffic_fabric_source": fabric_src, "traffic_fabric_fresh": fabric_fresh,
             "compulsory_bytes_per_launch": compulsory,
             "frac_compulsory": None if compulsory is None else compulsory * per_s / HBM_PEAK_GBPS,
@@ -710,7 +884,7 @@ def main():
                        + " + k_spmm_fix") if parallelism == "single"
                       else "one distributed SpMM on this rank: local SpMM launches + the exchange",
             # secondary denominator: this box's device-to-device copy rate (read + write)
-            "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps,
+            "device_copy_GBps": copy_gbps, "frac_of_device_copy": ach_alg / copy_gbps,
             # the measured HBM rate of the launch against what a plain copy reaches on THIS box
             "frac_hbm_of_device_copy": None if hbm_bytes is None else hbm_bytes * per_s / copy_gbps,
             "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
@@ -750,9 +924,12 @@ def main():
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
             "exchange_selection": exchange_selection,
+            "rccl": rccl,
+            "setup_s": setup_s,
         }
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
-            out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E)
+            out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E,
+                                               full={"auto": "auto", "full": True, "sample": False}[args.cpu_ref])
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytextgcn_amd import Text2GraphTransformer, optim, synth  # noqa: E402
-from pytextgcn_amd.sharded import ShardedGCN, ShardedGraph, sharded_cross_entropy  # noqa: E402
+from pytextgcn_amd.sharded import ShardedGCN, ShardedGraph, init_process_group, sharded_cross_entropy  # noqa: E402
 
 p = argparse.ArgumentParser()
 p.add_argument("--docs", type=int, default=20000)
@@ -34,10 +34,8 @@ th.cuda.set_device(dev_index)
 dev = th.device("cuda", dev_index)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29577")
-if args.backend == "nccl":
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-else:
-    dist.init_process_group(args.backend, rank=rank, world_size=world)
+# RCCL on a high-priority stream: the exchange must be scheduled while the local SpMM grids fill the CUs
+init_process_group(args.backend, dev, rank=rank, world_size=world)
 
 seed, lr, dropout, n_classes = 44, 0.05, 0.5, 6
 th.manual_seed(seed + rank)                        # dropout streams differ per rank

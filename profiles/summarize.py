@@ -82,6 +82,20 @@ def main():
         lines += ["", f"`{kname}` dispatches: {len(dur)}; durations (us), in launch order:", "",
                   "`" + " ".join(f"{d:.0f}" for d in dur) + "`"]
     out = {"tag": tag}
+    # average duration of the SpMM kernels in the stats pass, and the launch time the bench itself measured with HIP
+    # events in that very run (its JSON line in stats.log): both go into traffic.json, so that the roofline fraction can
+    # be recomputed from that file alone
+    out["kernel_avg_us"] = {short(r["Name"]).split("<")[0]: float(r["AverageNs"]) / 1e3 for r in rows
+                            if "k_spmm" in r["Name"]}
+    slog = os.path.join(stats_dir, "..", "stats.log")
+    if os.path.exists(slog):
+        for ln in open(slog):
+            ln = ln.strip()
+            if ln.startswith("{") and '"roofline"' in ln:
+                try:
+                    out["bench_launch_ms"] = json.loads(ln)["roofline"]["launch_ms"]
+                except (ValueError, KeyError):
+                    pass
     if len(sys.argv) >= 5:
         fe, wr = counters(sys.argv[3]), counters(sys.argv[4])
         lines += ["", "## PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE in KiB per dispatch (TCC_* in requests)", "",
@@ -140,7 +154,15 @@ def update_traffic(key, tag, out):
                   "calibrate_fetch.py). Counts L2<->fabric requests, Infinity-Cache hits included: an upper bound on HBM "
                   "bytes (the live HBM figure is bench.py's roofline.hbm_activity).",
         "fetch_size_kib": fetch, "write_size_kib": write, "round": tag,
+        # one launch = the sum of its kernels' average durations in the --kernel-trace --stats pass of the same command,
+        # next to the HIP-event launch time bench.py measured in that pass: fabric GB/s = bytes_per_launch / launch time
+        "kernel_avg_us": out.get("kernel_avg_us"),
+        "launch_ms_rocprof_kernel_sum": (sum(out["kernel_avg_us"].values()) / 1e3) if out.get("kernel_avg_us") else None,
+        "launch_ms_bench_hip_events": out.get("bench_launch_ms"),
         "kernel_sha16": bench.spmm_kernel_sha16()}
+    t = db[key]["launch_ms_rocprof_kernel_sum"]
+    if t:
+        db[key]["fabric_GBps_at_rocprof_launch_time"] = total / (t * 1e-3) / 1e9
     with open(path, "w") as f:
         json.dump(db, f, indent=1)
     print(f"profiles/traffic.json[{key}] = {total / 1e9:.3f} GB per launch ({tag}, kernels {db[key]['kernel_sha16']})")

@@ -437,12 +437,19 @@ Knobs knobs_from_env() {
     return k;
 }
 
-int item_weight_from_env() {
+// Non-zeros + rows per wavefront task.  TGCN_ITEM_WEIGHT pins it; otherwise it follows the size of the operator:
+//   * 384 for whole-graph operators (round-2 re-sweep on c4, profiles/r02r_resweep_items.log: 384 / 32 is 3 % faster at
+//     F = 200 and 2 % slower at F = 64 than round 1's 512 / 64);
+//   * 128 for operators below 24 M entries + rows -- the per-rank operators A_r / B_r of the 1-D partition (c4 over 8
+//     ranks: 2.2 M and 4.4 M entries).  At 384 such an operator is ~10 k tasks for 8 192 resident wavefronts: one round
+//     with a ragged tail.  Measured per rank (tools/sim_shard_compute.py --item-weights, profiles/r04_item_weight_sweep.log):
+//     8 ranks 0.644 -> 0.597 ms per distributed SpMM at F = 200 (0.246 -> 0.229 at F = 64), 4 ranks 1.151 -> 1.105,
+//     2 ranks 2.142 -> 2.073; 96 is level with 128, 64 slower again.
+int item_weight_for(const CsrBlock &b) {
     const char *s = std::getenv("TGCN_ITEM_WEIGHT");
-    int v = s ? std::atoi(s) : 0;
-    if (v < 64 || v > (1 << 20)) v = 384;   // round-2 re-sweep (profiles/r02r_resweep_items.log): 384 / 32 is 3 % faster at
-                                            // F = 200 and 2 % slower at F = 64 than round 1's 512 / 64
-    return v;
+    const int v = s ? std::atoi(s) : 0;
+    if (v >= 64 && v <= (1 << 20)) return v;
+    return b.nnz + b.n_rows < (int64_t(24) << 20) ? 128 : 384;
 }
 
 }  // namespace
@@ -862,7 +869,6 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
     (void)hipFree(vals_a.release());
     (void)hipFree(vals_b.release());
 
-    const int T = item_weight_from_env();
     const bool whole = row_begin == 0 && row_end == N;
     if (whole) {
         plan.fwd.n_rows = n_rows;
@@ -875,7 +881,7 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
         TGCN_CHECK(take_block(rowptr.as<int32_t>(), cv.as<int2>(), N, row_begin, row_end, plan.fwd,
                               stream));
     }
-    TGCN_CHECK(build_items(plan.fwd, T, stream));
+    TGCN_CHECK(build_items(plan.fwd, item_weight_for(plan.fwd), stream));
     if (with_transpose && !plan.symmetric) {
         if (whole) {
             plan.bwd.n_rows = n_cols;
@@ -888,7 +894,7 @@ int plan_create_impl(int64_t n_rows, int64_t n_cols, int64_t E, const int64_t *s
             TGCN_CHECK(take_block(rowptr_t.as<int32_t>(), cv_t.as<int2>(), N, row_begin, row_end,
                                   plan.bwd, stream));
         }
-        TGCN_CHECK(build_items(plan.bwd, T, stream));
+        TGCN_CHECK(build_items(plan.bwd, item_weight_for(plan.bwd), stream));
     }
     return TGCN_OK;
 }

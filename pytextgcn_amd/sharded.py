@@ -37,6 +37,32 @@ from torch import Tensor, nn
 from .conv import glorot_
 
 
+def init_process_group(backend: str = "nccl", device: Optional[torch.device] = None, timeout_s: Optional[float] = None,
+                       **kw) -> None:
+    """torch.distributed.init_process_group for the 1-D partition.  With RCCL (backend "nccl") the communicator's
+    kernels go on a HIGH-PRIORITY stream: the local SpMM grids fill all 256 CUs, and a collective enqueued at normal
+    priority gets CUs only as SpMM waves drain -- the overlap `all-gather || A_r`, `reduce-scatter || B_r` that
+    `ShardedGraph.spmm` is built around would run one phase after the other.  `timeout_s` bounds every collective (a
+    dead peer then ends the process instead of hanging it)."""
+    import datetime
+    if timeout_s is not None:
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+    if backend != "nccl":
+        dist.init_process_group(backend, **kw)
+        return
+    if device is not None:
+        kw["device_id"] = device
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except (AttributeError, TypeError):
+        pass
+    try:
+        dist.init_process_group("nccl", pg_options=opts, **kw)
+    except TypeError:                      # a torch that spells the argument differently: default options
+        dist.init_process_group("nccl", **kw)
+
+
 # --------------------------------------------------------------------------------------------------
 # local-operator engine: the HIP library.  (tests inject a CPU engine built on the oracle to run the
 # partition + exchange logic under gloo without a GPU; the package itself ships no CPU engine.)
@@ -785,13 +811,34 @@ class ShardedGraph:
                 pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
         whole = self._whole_operand(d, x_local)                # narrow widths: own rows copied behind the hub block
         gathered()
-        if whole is not None:
-            y = d.B.spmm(whole, bias)                                       # overlaps the reduce-scatter
-        else:
-            # split operand: hub columns from the gathered block, own regular columns straight from x_local
-            y = d.B.spmm(xbuf, bias, x2=x_local[hp:] if rp > 0 else None)
+        y = self._apply_B(d, x_local, bias, xbuf, whole)                    # overlaps the reduce-scatter
         for finish in pending:
             finish(y[:hp])
+        return y
+
+    def _apply_B(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor], xbuf: Tensor, whole: Optional[Tensor]) -> Tensor:
+        if whole is not None:
+            return d.B.spmm(whole, bias)
+        # split operand: hub columns from the gathered block, own regular columns straight from x_local
+        return d.B.spmm(xbuf, bias, x2=x_local[self.hp:] if self.rp > 0 else None)
+
+    def local_step(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor], gathered: Tensor, rs_out: Tensor) -> Tensor:
+        """Every launch one distributed SpMM makes on this rank EXCEPT the collectives, whose results are handed in
+        (`gathered`: the hub block [W * hp, F] -- for narrow widths the leading part of a [W * hp + rp, F] buffer --,
+        `rs_out`: the reduce-scattered hub sums [hp, F]): the compute side of the step, for measurements on one
+        device (tools/sim_shard_compute.py)."""
+        hp, rp = self.hp, self.rp
+        if d.A is not None:
+            xr = x_local[hp:]
+            for ch in d.chunks[self.rs_chunks]:
+                ch.op.spmm(xr)
+        whole = None
+        if rp > 0 and x_local.size(1) <= self._NARROW:
+            whole = gathered._base if gathered._base is not None else gathered
+            whole[self.world * hp:].copy_(x_local[hp:])
+        y = self._apply_B(d, x_local, bias, gathered, whole)
+        if d.A is not None:
+            y[:hp] += rs_out
         return y
 
     def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):

@@ -601,9 +601,12 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3
     # M applied to constant columns = row sums of M, checked against the exported CSR
     rp, col, val = plan.export_csr()
-    rowsum = torch.zeros(N, device=cuda, dtype=torch.float64)
-    rows = torch.repeat_interleave(torch.arange(N, device=cuda), (rp[1:] - rp[:-1]).long())
-    rowsum.index_add_(0, rows, val.double())
+    # (row sums as differences of a float64 running sum: 52 M float64 atomics on a handful of hub addresses -- an
+    # index_add_ -- took 196 s of this test's 235 s)
+    cs = torch.zeros(plan.nnz + 1, device=cuda, dtype=torch.float64)
+    torch.cumsum(val.double(), 0, out=cs[1:])
+    rowsum = cs[rp[1:].long()] - cs[rp[:-1].long()]
+    del cs
     ones = plan.spmm(torch.ones(N, 4, device=cuda))
     assert rel_err(ones[:, 0], rowsum.float()) < TOL
     # sampled rows (the heaviest word rows and random ones) against a float64 gather on the GPU
@@ -613,7 +616,7 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
         s, e = rp[r].item(), rp[r + 1].item()
         ref = (val[s:e].double().unsqueeze(1) * x[col[s:e].long()].double()).sum(0)
         assert rel_err(mx[r], ref.float()) < TOL, r          # one row: this IS the row-relative error
-    del rows, rowsum
+    del rowsum
 
 
 def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=None, case=None):

@@ -248,6 +248,37 @@ def test_bench_launches_its_own_ranks_for_n_gt_1():
     assert rec == {"launch_check": True, "n_gpus": 2}
 
 
+@pytest.mark.parametrize("fail", ["exit", "hang"])
+def test_bench_falls_back_to_the_plain_configuration_when_the_first_attempt_dies_or_hangs(fail):
+    """The N > 1 measurement must not be lost to one bad attempt (the driver's scaling run is one shot): a child whose
+    last rank exits with an error -- or hangs past the wall budget while its peer waits in a collective -- is ended by
+    its process group, a fresh child runs the plain configuration (TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1
+    --no-epoch) and its record is relayed with the reason in `"fallback"`.  Rendezvous only (--launch-check): no GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TGCN_BENCH_TEST_FAIL=fail, TGCN_BENCH_BUDGET_S="20")
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] is True and rec["n_gpus"] == 2
+    assert ("budget" in rec["fallback"]) if fail == "hang" else ("exited with code" in rec["fallback"])
+    assert time.time() - t0 < 200
+    # without the fallback the failure is the caller's to see
+    env["TGCN_BENCH_NO_FALLBACK"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert res.returncode != 0 and not res.stdout.decode().strip()
+
+
 def test_bench_knows_every_baseline_configuration():
     import importlib.util
     import os
