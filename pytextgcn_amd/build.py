@@ -51,8 +51,13 @@ def check_asm_ring_kernels(remarks: str) -> None:
         if not _RING_KERNEL.search(name):
             continue
         seen += 1
-        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
-        vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        m_scratch = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
+        m_vspill = re.search(r"VGPRs Spill: (\d+)", b)
+        if m_scratch is None or m_vspill is None:
+            # another hipcc may word its remarks differently: say so instead of dying on `None.group`
+            raise RuntimeError(f"build check: the kernel-resource-usage remark of {name} carries no "
+                               "'ScratchSize [bytes/lane]' / 'VGPRs Spill' field (has hipcc changed its wording?)")
+        scratch, vspill = int(m_scratch.group(1)), int(m_vspill.group(1))
         if scratch or vspill:
             bad.append(f"{name}: scratch {scratch} B/lane, {vspill} VGPRs spilled")
     if seen == 0:

@@ -638,6 +638,159 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same product through LDS stages with the ROWS split over the waves (round 4; the default fp32 path whenever
+// the operands are 16-byte friendly).  k_gemm_tn_partial above gives wave w the M tiles {w, w + 4}: at k = 200 (7 M
+// tiles) the four waves issue 16 tile products per row pair for the 14 that exist, every fragment is a 4-byte global
+// load of a 128-byte row piece, and the matrix pipe is 53 % busy (profiles/r02_pmc_gemm_c4.md).  Here a stage of 32 rows
+// of A and G is copied by the whole workgroup with 16-byte loads into a double-buffered LDS image (the loads of stage
+// s + 1 are in flight under the MFMAs of stage s), and wave w = (t, par) owns column tile t of G and the row pairs
+// p = par (mod PAR) of every stage for ALL M tiles: mt MFMAs per row pair and wave, none wasted, every wave the same
+// load.  The PAR row classes are added in a fixed order through LDS at the end (deterministic).
+// NT = number of 32-column tiles of G (1, 2 or 4; PAR = 4 / NT).  k, n, lda, ldg multiples of 4, 16-byte aligned bases.
+// Fragments past k / n read whatever follows in the LDS image: they only feed rows >= k / columns >= n of the padded
+// result tile, which nobody reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTnStageRows = 32;
+
+inline size_t tn_staged_lds_bytes(int k, int n) {
+    const size_t stage = size_t(2) * kTnStageRows * ((k + 4) + (n + 4)) + 64;        // + over-read pad
+    const size_t reduce = size_t(2) * ((k + 31) / 32) * 1024;                        // two waves' accumulator tiles
+    return sizeof(float) * std::max(stage, reduce);
+}
+
+template <int NT, int MT, bool DROP>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restrict__ A, int64_t lda,
+                                                           const float *__restrict__ G, int64_t ldg, int64_t N, int k,
+                                                           int n, int64_t rows_per_wg, float *__restrict__ partial,
+                                                           const Drop drop, const int k0) {
+    extern __shared__ __align__(16) float tn_lds[];
+    constexpr int PAR = 4 / NT, SR = kTnStageRows;       // MT: accumulator tiles held (>= the M tiles of k: 4, 7 or 8)
+    uint32_t s_lo = 0, s_hi = 0;
+    if constexpr (DROP) {
+        const uint64_t sd = *drop.seed;
+        s_lo = uint32_t(sd);
+        s_hi = uint32_t(sd >> 32);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int t = wave % NT, par = wave / NT;
+    const int mt = (k + 31) / 32;
+    constexpr int npad = 32 * NT;
+    const int mpad = 32 * mt;
+    const int kp = k + 4, np_ = n + 4;                       // LDS row pitches (multiples of 4: 16-byte stores)
+    const int stage_floats = SR * (kp + np_);
+    const int64_t r_begin = int64_t(blockIdx.x) * rows_per_wg;
+    const int64_t r_end = std::min(N, r_begin + rows_per_wg);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    // global -> registers -> LDS.  A: wave w copies rows w, w + 4, ... of the stage, lane j the j-th float4 of the row
+    // (k / 4 <= 64 of them); G: 16 lanes per row... generally n / 4 <= 32 float4s per row, two rows per wave pass.
+    constexpr int AV = SR / 4, GV = SR / 8;
+    const int k4 = k >> 2, n4 = n >> 2;
+    const bool a_on = lane < k4;
+    const int g_sub = lane >> 5, g_j = lane & 31;            // G: lanes 0-31 one row, lanes 32-63 the next
+    const bool g_on = g_j < n4;
+    float4 ra[AV], rg[GV];
+    auto fetch = [&](int64_t row0) {                          // zeros past the slice
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            const int64_t row = row0 + wave + 4 * u;
+            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_on && row < r_end) ra[u] = *reinterpret_cast<const float4 *>(A + row * lda + 4 * lane);
+        }
+#pragma unroll
+        for (int u = 0; u < GV; ++u) {
+            const int64_t row = row0 + 2 * wave + g_sub + 8 * u;
+            rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_on && row < r_end) rg[u] = *reinterpret_cast<const float4 *>(G + row * ldg + 4 * g_j);
+        }
+    };
+    // the fused dropout masks A on its way into LDS: every element is hashed ONCE per workgroup, by the thread that
+    // copies it (masking the fragments as they are read would hash every element once per column-tile wave)
+    auto deposit = [&](int buf, int64_t row0) {
+        float *la = tn_lds + buf * stage_floats, *lg = la + SR * kp;
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            if (a_on) {
+                float4 v = ra[u];
+                if constexpr (DROP) {
+                    const uint32_t key = drop_row_key(s_lo, s_hi, row0 + wave + 4 * u);
+                    v.x = drop_elem(v.x, key, drop_col_term(k0 + 4 * lane), drop);
+                    v.y = drop_elem(v.y, key, drop_col_term(k0 + 4 * lane + 1), drop);
+                    v.z = drop_elem(v.z, key, drop_col_term(k0 + 4 * lane + 2), drop);
+                    v.w = drop_elem(v.w, key, drop_col_term(k0 + 4 * lane + 3), drop);
+                }
+                *reinterpret_cast<float4 *>(la + (wave + 4 * u) * kp + 4 * lane) = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GV; ++u)
+            if (g_on) *reinterpret_cast<float4 *>(lg + (2 * wave + g_sub + 8 * u) * np_ + 4 * g_j) = rg[u];
+    };
+    auto compute = [&](int buf) {
+        const float *la = tn_lds + buf * stage_floats + half * kp + c;
+        const float *lg = tn_lds + buf * stage_floats + SR * kp + half * np_ + 32 * t + c;
+#pragma unroll
+        for (int q = 0; q < SR / 2 / PAR; ++q) {
+            const int p = par + PAR * q;                      // row pair of the stage: rows 2 p, 2 p + 1
+            const float gv = lg[2 * p * np_];
+            const float *ar = la + 2 * p * kp;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < mt) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32 * m], gv, acc[m], 0, 0, 0);
+        }
+    };
+    if (r_end > r_begin) {
+        const int64_t n_st = (r_end - r_begin + SR - 1) / SR;
+        fetch(r_begin);
+        deposit(0, r_begin);
+        __syncthreads();
+        for (int64_t it = 0; it < n_st; ++it) {
+            if (it + 1 < n_st) fetch(r_begin + SR * (it + 1));      // in flight under the MFMAs of this stage
+            compute(int(it & 1));
+            if (it + 1 < n_st) deposit(int((it + 1) & 1), r_begin + SR * (it + 1));
+            __syncthreads();
+        }
+    }
+    // add the row classes: par in [s, 2 s) hands its tiles to par - s through LDS, s = PAR / 2, PAR / 4, ... (fixed order)
+#pragma unroll
+    for (int s = PAR / 2; s >= 1; s >>= 1) {
+        float *red = tn_lds + ((par - s) * NT + t) * (mt * 1024) + lane;
+        if (par >= s && par < 2 * s) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) red[(m * 16 + i) * 64] = acc[m][i];
+        }
+        __syncthreads();
+        if (par < s) {
+            const float *src = tn_lds + (par * NT + t) * (mt * 1024) + lane;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][i] += src[(m * 16 + i) * 64];
+        }
+        __syncthreads();
+    }
+    if (par == 0) {
+        float *out = partial + int64_t(blockIdx.x) * mpad * npad;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (m < mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int orow = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    out[orow * npad + 32 * t + c] = acc[m][i];
+                }
+    }
+}
+
 // The tn product with split-bf16 operands (see k_gemm_tall_split): the reduction index is the ROW, so a K step of
 // v_mfma_f32_32x32x16_bf16 is 16 rows.  A stage = 32 rows (two K steps) of A (contiguous: 32 k floats) and of G,
 // copied by the whole workgroup with 16-byte loads into a double-buffered LDS image (row pitch k + 4 / n + 4: the
@@ -1118,6 +1271,38 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
             const int ng = std::min(kGroupCols, n - j0);
             const int ntg = (ng + 31) / 32, mtg = (kg + 31) / 32;
             const float *Ag = A + i0, *Gg = G + j0;
+            // 16-byte friendly operands with 1, 2 or 4 column tiles of G: the LDS-staged kernel (rows split over the waves)
+            const bool staged = (ntg == 1 || ntg == 2 || ntg == 4) && kg % 4 == 0 && ng % 4 == 0 && lda % 4 == 0 &&
+                                ldg % 4 == 0 && reinterpret_cast<uintptr_t>(Ag) % 16 == 0 &&
+                                reinterpret_cast<uintptr_t>(Gg) % 16 == 0 && tn_staged_lds_bytes(kg, ng) <= 160 * 1024 &&
+                                std::getenv("TGCN_TN_STAGED_OFF") == nullptr;
+            if (staged) {
+                const int64_t rpw = ((N + nb - 1) / nb + kTnStageRows - 1) / kTnStageRows * kTnStageRows;
+                const size_t lb = tn_staged_lds_bytes(kg, ng);
+#define TGCN_TNS(NT, MT_, DR)                                                                                         \
+    do {                                                                                                              \
+        TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_staged<NT, MT_, DR>),           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));       \
+        k_gemm_tn_staged<NT, MT_, DR><<<nb, 256, lb, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rpw, partial,                 \
+                                                          drop ? *drop : Drop{}, i0);                               \
+    } while (0)
+#define TGCN_TNS_M(NT, DR)                                                                                            \
+    do {                                                                                                              \
+        if (mtg <= 4) TGCN_TNS(NT, 4, DR); else if (mtg <= 7) TGCN_TNS(NT, 7, DR); else TGCN_TNS(NT, 8, DR);         \
+    } while (0)
+                if (drop) {
+                    if (ntg == 1) TGCN_TNS_M(1, true); else if (ntg == 2) TGCN_TNS_M(2, true); else TGCN_TNS_M(4, true);
+                } else {
+                    if (ntg == 1) TGCN_TNS_M(1, false); else if (ntg == 2) TGCN_TNS_M(2, false); else TGCN_TNS_M(4, false);
+                }
+#undef TGCN_TNS_M
+#undef TGCN_TNS
+                TGCN_HIP_CHECK(hipGetLastError());
+                k_gemm_tn_reduce<<<(kg * ng + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mtg, 32 * ntg, kg, ng,
+                                                                     C + int64_t(i0) * ldc + j0, ldc);
+                TGCN_HIP_CHECK(hipGetLastError());
+                continue;
+            }
 #define TGCN_TN(NT)                                                                                                   \
     do {                                                                                                              \
         if (drop)                                                                                                     \

@@ -317,6 +317,9 @@ def test_build_refuses_spills_in_the_asm_ring_kernels():
         build.check_asm_ring_kernels(remark(ring, 0, 0) + remark(split, 0, 2))
     with pytest.raises(RuntimeError, match="no kernel-resource-usage remarks"):
         build.check_asm_ring_kernels(remark(loop, 0, 0))
+    # a remark block without the two fields (another compiler release's wording) is a clear error, not an AttributeError
+    with pytest.raises(RuntimeError, match="carries no"):
+        build.check_asm_ring_kernels(remark(ring, 0, 0).replace("ScratchSize [bytes/lane]", "Scratch bytes per lane"))
 
 
 def test_counter_traffic_on_file_belongs_to_the_current_kernels():
