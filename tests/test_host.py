@@ -363,6 +363,46 @@ def test_committed_round3_bench_line_names_the_basis_of_its_roofline_fraction():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["csr"]["value"] > c["value"] > 0
 
 
+def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
+    """profiles/r04_bench_c4_n1.json (one MI355X, final round-4 library).  The roofline object as frozen in round 4:
+    `achieved` IS the GB/s `frac` is a fraction of (`frac == achieved / peak`, `achieved == traffic / launch time`), on
+    the basis `frac_basis` names -- the counter traffic of profiles/traffic.json, collected on these kernel sources --;
+    the algorithmic / fabric / HBM / compulsory figures stand side by side, each consistent with its byte count; nothing
+    is capped (`non_physical` would say so); traffic.json alone reproduces the fraction (it carries the launch time of
+    the counter run); the CPU-ref baseline ran on the FULL operator; the record says who took part."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r04_bench_c4_n1.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "setup_s"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 50_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    per_s = 1.0 / (r["launch_ms"] * 1e-3) / 1e9
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert r["frac_basis"] == "fabric" and r["traffic_fabric_fresh"] is True and r["non_physical"] is False
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["traffic"] * per_s) < 1e-6 * r["achieved"]
+    assert r["achieved"] == r["achieved_fabric"] and r["frac"] == r["frac_fabric"]
+    assert abs(r["achieved_algorithmic"] - r["algorithmic_bytes_per_launch"] * per_s) < 1e-6 * r["achieved_algorithmic"]
+    assert abs(r["frac_algorithmic"] - r["achieved_algorithmic"] / r["peak"]) < 1e-12
+    assert abs(r["frac_hbm"] - r["achieved_hbm"] / r["peak"]) < 1e-12
+    assert r["frac_compulsory"] < r["frac_hbm"] < r["frac_fabric"] <= 1.0 < r["frac_algorithmic"]
+    assert abs(r["frac_fabric_of_gather_ceiling"] - r["achieved_fabric"] / r["fabric_gather_ceiling_GBps"]) < 1e-12
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))["c4_n1"]
+    assert t["bytes_per_launch"] == r["traffic"]
+    # the counter run's own launch time (rocprof kernel sum ~ HIP events of the bench inside that run) gives the same rate
+    assert abs(t["launch_ms_rocprof_kernel_sum"] - t["launch_ms_bench_hip_events"]) < 0.02 * t["launch_ms_bench_hip_events"]
+    assert abs(t["fabric_GBps_at_rocprof_launch_time"] - r["achieved"]) < 0.03 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["full_operator"] is True and "FULL operator" in c["sample"] and c["cores"] >= 1
+    assert c["csr"]["value"] > c["value"] > 0
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["distinct_devices"] == 1 and d["rccl"]["devices"][0]["pci_bus_id"]
+    assert d["epoch_ms_fused_w1_update_in_backward_with_activation_reuse"] < d["epoch_ms_fused"] < d["epoch_ms"]
+
+
 def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():
     """plan.alloc_padded / padded_base (odd layer widths): the [n, F] view is the leading part of a zero-padded
     [n, F4] buffer; the buffer is given back for exactly that view and for nothing that merely looks like it."""

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pytextgcn_amd import synth  # noqa: E402
 from pytextgcn_amd.plan import GraphPlan  # noqa: E402
 from tools.sweep_spmm import time_spmm  # noqa: E402

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pytextgcn_amd.functional import masked_cross_entropy  # noqa: E402
 
 dev = "cuda:0"

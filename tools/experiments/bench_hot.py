@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the dense hot block on c4: TGCN_HOT_ROWS=0 / default, F = 200 and 64.
-Run each setting in its own process (the knobs are read once):  python tools/bench_hot.py"""
+Run each setting in its own process (the knobs are read once):  python tools/experiments/bench_hot.py"""
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import sys, torch
 sys.path.insert(0, %r)

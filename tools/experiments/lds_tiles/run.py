@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of "X tiles staged in LDS" on config c4, F = 200 (tools/exp_lds_tiles/gather_lds.hip, an experiment outside
+"""A/B of "X tiles staged in LDS" on config c4, F = 200 (tools/experiments/lds_tiles/gather_lds.hip, an experiment outside
 libtgcn.so): the same simplified gather kernel with the R most-gathered operand rows in LDS against R = 0, in the two
 workgroup shapes round 1 had tried, next to the product's tgcn_spmm on the same operator.  Results are checked against
 the R = 0 run (bit for bit: the arithmetic is the same) before they are timed.
-    python tools/exp_lds_tiles/run.py > profiles/r04_exp_lds_tiles.log"""
+    python tools/experiments/lds_tiles/run.py > profiles/r04_exp_lds_tiles.log"""
 import ctypes
 import json
 import os
@@ -13,7 +13,7 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, ROOT)
 from pytextgcn_amd import synth  # noqa: E402
 from pytextgcn_amd.plan import GraphPlan  # noqa: E402

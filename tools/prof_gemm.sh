@@ -8,7 +8,7 @@ cd /tmp
 i=0
 while IFS= read -r set; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $root/$R/pass$i -- python3 $root/tools/bench_dense.py > $root/$R/pass$i.log 2>&1 || { tail -3 $root/$R/pass$i.log; }
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $root/$R/pass$i -- python3 $root/tools/experiments/bench_dense.py > $root/$R/pass$i.log 2>&1 || { tail -3 $root/$R/pass$i.log; }
 done <<'SETS'
 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE
