@@ -125,7 +125,8 @@ def launch_ranks(args) -> int:
     env.setdefault("OMP_NUM_THREADS", "4")
     budget = float(os.environ.get("TGCN_BENCH_BUDGET_S", "420"))
     t0 = time.time()
-    rc, text = _run_ranks(command([]), env, budget)
+    # the ranks may try every form of the exchange: this process watches them and has a plain run to fall back on
+    rc, text = _run_ranks(command([]), dict(env, TGCN_BENCH_WATCHDOG="1"), budget)
     record = _last_record(text)
     if rc == 0 and record is not None:
         print(json.dumps(record), flush=True)
@@ -727,7 +728,13 @@ def main():
     # steps of each decide (max over ranks, the same answer on every rank).  TGCN_EXCHANGE pins the form.
     exchange_selection = None
     if world > 1 and "TGCN_EXCHANGE" not in os.environ:
-        forms = list(sg.EXCHANGES)                  # "collective" first: RCCL's own collectives with A_r in one piece
+        # Which forms are tried.  Started by launch_ranks() (a parent with a wall budget and a fallback run watches):
+        # all of them.  Started directly under `python -m torch.distributed.run` there is nobody to fall back on if a
+        # pairwise / all-to-all form hangs on this node, and a lost run is worse than a slower exchange: RCCL's own
+        # collectives only (with A_r in 1 / 2 / 4 row chunks) unless TGCN_BENCH_TRY_ALL_FORMS=1 asks for the rest.
+        watched = os.environ.get("TGCN_BENCH_WATCHDOG") == "1" or os.environ.get("TGCN_BENCH_TRY_ALL_FORMS") == "1"
+        forms = list(sg.EXCHANGES) if (watched or backend != "nccl") else ["collective"]
+        # "collective" first: RCCL's own collectives with A_r in one piece
         chunkings = [1, 2, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
         trial = {}                                 # is the configuration the fallback of launch_ranks() runs, too
         for K in chunkings:
@@ -764,7 +771,8 @@ def main():
         sg.exchange = best.split("/")[0]
         sg.set_rs_chunks(int(best.split("/")[1]))
         sg.drop_unused_chunks()                    # the chunk operators of the counts that lost are dead weight
-        exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows()}
+        exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows(),
+                              "forms_tried": forms, "watched_by_launcher": os.environ.get("TGCN_BENCH_WATCHDOG") == "1"}
         parallelism = (f"row{world}: " + ("hubs(words) replicated, hub rows reduce-scattered" if sg.rp > 0 else
                                           "no hub structure: operand rows exchanged") +
                        f" (exchange form / A_r row chunks = {best}, the fastest of {trial})")

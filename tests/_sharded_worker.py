@@ -130,6 +130,7 @@ def check(kind, device="cpu"):
         assert rel_err(got, ref) < 1e-5, (kind, transpose, rel_err(got, ref))
 
     check_exchange_forms(sg, x, b)
+    check_offline_construction(sg, g, hubs, N)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
     torch.manual_seed(3)
@@ -206,6 +207,26 @@ def check(kind, device="cpu"):
         sg.spmm = real_spmm
 
 
+def check_offline_construction(sg, g, hubs, N, engine=None):
+    """`ShardedGraph.for_rank` -- what the at-size GPU tests and tools/sim_shard_compute.py inspect -- builds, WITHOUT the
+    peers, exactly what the collective constructor built on this rank: the same partition, the same local operators, the
+    same referenced columns, and gather-side halo lists equal to the ones the ranks swapped."""
+    off = sharded.ShardedGraph.for_rank(g.edge_index, g.edge_attr, N, sg.world, sg.rank, hubs=hubs,
+                                        engine=engine if engine is not None else OracleEngine(), halo_lists=True)
+    assert (off.hp, off.rp, off.symmetric, len(off.dirs)) == (sg.hp, sg.rp, sg.symmetric, len(sg.dirs))
+    assert torch.equal(off.owned, sg.owned)
+    for d_off, d_on in zip(off.dirs, sg.dirs):
+        assert torch.equal(d_off.need_cols, d_on.need_cols)
+        assert d_off.need_counts_l == d_on.need_counts_l and d_off.send_counts_l == d_on.send_counts_l
+        assert torch.equal(d_off.send_slots.cpu(), d_on.send_slots.cpu())
+        for a, b in ((d_off.A, d_on.A), (d_off.B, d_on.B)):
+            assert (a is None) == (b is None)
+            if a is not None and hasattr(a, "csr"):
+                assert all(torch.equal(u, v) for u, v in zip(a.csr, b.csr))
+            elif a is not None:
+                assert all(torch.equal(u, v) for u, v in zip(a.export_csr(), b.export_csr()))
+
+
 def check_exchange_forms(sg, x_full, bias):
     """Every form of the exchange gives the same distributed SpMM: the pairwise and the halo form (index lists,
     pruned reduce-scatter), with A_r in one or several row chunks, are bit-for-bit alike (both add the ranks' partial
@@ -258,6 +279,18 @@ def check_hip(kind, g, hubs, N, dev):
         got = sg.gather_rows(sg.spmm(sg.scatter_rows(x.to(dev)), b.to(dev), transpose=transpose))
         assert rel_err(got.cpu(), ref) < 1e-5, (kind, transpose, rel_err(got.cpu(), ref))
     check_exchange_forms(sg, x, b)
+    check_offline_construction(sg, gd, None if hubs is None else hubs.to(dev), N, engine=sharded.HipEngine())
+    # the reference-order normalisation through the partition: PyG's sequential fp32 degree sums and its association
+    # (not symmetric: M^T gets operators of its own); the weights are the oracle's bits, so what is left against the
+    # oracle is the summation order of the SpMM alone
+    sgr = sharded.ShardedGraph(gd.edge_index, gd.edge_attr, N, hubs=None if hubs is None else hubs.to(dev),
+                               degree_sum="reference")
+    assert len(sgr.dirs) == 2 and not sgr.symmetric
+    for transpose in (False, True):
+        ref = O.propagate(nei.flip(0) if transpose else nei, x, nw, N) + b
+        got = sgr.gather_rows(sgr.spmm(sgr.scatter_rows(x.to(dev)), b.to(dev), transpose=transpose))
+        assert rel_err(got.cpu(), ref) < 2e-6, (kind, transpose, rel_err(got.cpu(), ref))
+    del sgr
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
