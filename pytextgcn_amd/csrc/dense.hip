@@ -79,6 +79,15 @@ __device__ __forceinline__ uint32_t drop_row_key(uint32_t s_lo, uint32_t s_hi, i
     return h;
 }
 
+// the same key for a row index that is the same in every lane of the wave (the LDS-staged tn kernels: a wave copies whole
+// rows): forced into scalar registers, so that the three multiplies run on the scalar unit instead of as quarter-rate
+// vector instructions in all 64 lanes
+__device__ __forceinline__ uint32_t drop_row_key_uniform(uint32_t s_lo, uint32_t s_hi, int64_t row) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(row)));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(uint64_t(row) >> 32)));
+    return drop_row_key(s_lo, s_hi, int64_t((uint64_t(hi) << 32) | lo));
+}
+
 __device__ __forceinline__ uint32_t drop_col_term(int col) { return uint32_t(col) * 0x9E3779B1u; }
 
 __device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t col_term, const Drop &d) {
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
             if (a_on) {
                 float4 v = ra[u];
                 if constexpr (DROP) {
-                    const uint32_t key = drop_row_key(s_lo, s_hi, row0 + wave + 4 * u);
+                    const uint32_t key = drop_row_key_uniform(s_lo, s_hi, row0 + wave + 4 * u);
                     v.x = drop_elem(v.x, key, drop_col_term(k0 + 4 * lane), drop);
                     v.y = drop_elem(v.y, key, drop_col_term(k0 + 4 * lane + 1), drop);
                     v.z = drop_elem(v.z, key, drop_col_term(k0 + 4 * lane + 2), drop);

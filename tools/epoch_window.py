@@ -26,19 +26,35 @@ n_ep = len(marks) - 1
 agg = defaultdict(lambda: [0, 0])
 busy = 0
 last_end = t0
+last_name = "(window start)"
 idle = 0
+gaps = defaultdict(lambda: [0, 0])       # (kernel before, kernel after) -> [ns, count]
+
+
+def _short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").replace("tgcn::", "").split("(")[0][:110]
+
+
 for s, e, n in rows:
     if s < t0 or s >= t1:
         continue
-    short = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("tgcn::", "").split("(")[0][:110]
+    short = _short(n)
     agg[short][0] += e - s
     agg[short][1] += 1
     busy += e - s
     if s > last_end:
         idle += s - last_end
+        g = gaps[(last_name[:60], short[:60])]
+        g[0] += s - last_end
+        g[1] += 1
+    if e >= last_end:
+        last_name = short
     last_end = max(last_end, e)
 print(f"window: {n_ep} epochs, {(t1 - t0) / n_ep / 1e6:.3f} ms per epoch, kernels {busy / n_ep / 1e6:.3f} ms, "
       f"idle between kernels {idle / n_ep / 1e6:.3f} ms")
+print("largest idle gaps (kernel before -> kernel after): us per epoch, occurrences per epoch")
+for (a, b), (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f"  {t / n_ep / 1e3:8.1f} us  x{c / n_ep:.1f}   `{a}` -> `{b}`")
 print("| kernel | us / epoch | calls / epoch |\n|---|---|---|")
 for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f"| `{k}` | {t / n_ep / 1e3:.1f} | {c / n_ep:.1f} |")
