@@ -276,19 +276,40 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             for (int i = 0; i < 16; ++i)
                 c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
         }
+        // The lane's first row and its address are formed ONCE per block; element (i, t) then sits at the wave-uniform
+        // offset ((i&3) + 8*(i>>2)) * ldc + 32 t from it (scalar arithmetic, one 64-bit add per store).  Round 4: written
+        // as `C[orow * ldc + col]` with a 64-bit `orow < N` test per element, hipcc emitted two quarter-rate 32-bit
+        // multiplies, a 64-bit multiply-add and an exec-mask branch in front of EVERY one of the 16 NT stores of a block --
+        // 5.8 vector-ALU instructions per MFMA in the plain nt kernel (profiles/r04_pmc_dense.md), and on this part vector-ALU
+        // issue time adds to the matrix pipe's instead of hiding under it.  (Variants tried on top and dropped because the
+        // asm-ring kernels then spill, which the build refuses: row keys handed round with wave shuffles instead of 16
+        // hashes per lane; scalar row bases + one 32-bit lane offset, which hipcc does not turn into saddr-form stores.)
+        const int64_t row0 = blk * 32 + 4 * half;
+        float *crow = C + row0 * ldc + r;
+        const bool whole_blk = blk * 32 + 32 <= N;          // wave-uniform: only the last block of the matrix is ragged
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = 32 * t + r;
             if (col < n) {
                 const uint32_t cterm = drop_col_term(p_col0 + col);
+                if (whole_blk) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int64_t orow = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    float out = acc[t][i];
-                    if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
-                    if (orow < N) {
-                        C[orow * ldc + col] = out;
+                    for (int i = 0; i < 16; ++i) {
+                        float out = acc[t][i];
+                        if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
+                        crow[int64_t((i & 3) + 8 * (i >> 2)) * ldc + 32 * t] = out;
                         if constexpr (COLSUM) csum[t] += out;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        float out = acc[t][i];
+                        if constexpr (DROP && TRANS_B) out = drop_elem(out, c_key[i], cterm, drop);
+                        if (row0 + ro < N) {
+                            crow[int64_t(ro) * ldc + 32 * t] = out;
+                            if constexpr (COLSUM) csum[t] += out;
+                        }
                     }
                 }
             }
