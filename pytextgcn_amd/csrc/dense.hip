@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
 constexpr int kTnStageRows = 32;
 
 inline size_t tn_staged_lds_bytes(int k, int n) {
-    const size_t stage = size_t(2) * kTnStageRows * ((k + 4) + (n + 4)) + 64;        // + over-read pad
+    const size_t stage = size_t(2) * kTnStageRows * ((k + 4) + (n + 4)) + 320;       // + over-read pad (<= 8 tiles of a row)
     const size_t reduce = size_t(2) * ((k + 31) / 32) * 1024;                        // two waves' accumulator tiles
     return sizeof(float) * std::max(stage, reduce);
 }
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
                                                            int n, int64_t rows_per_wg, float *__restrict__ partial,
                                                            const Drop drop, const int k0) {
     extern __shared__ __align__(16) float tn_lds[];
-    constexpr int PAR = 4 / NT, SR = kTnStageRows;       // MT: accumulator tiles held (>= the M tiles of k: 4, 7 or 8)
+    constexpr int PAR = 4 / NT, SR = kTnStageRows;       // MT: accumulator tiles held (>= the M tiles of k: 2, 4, 7 or 8)
     uint32_t s_lo = 0, s_hi = 0;
     if constexpr (DROP) {
         const uint64_t sd = *drop.seed;
@@ -725,18 +725,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
     const int g_sub = lane >> 5, g_j = lane & 31;            // G: lanes 0-31 one row, lanes 32-63 the next
     const bool g_on = g_j < n4;
     float4 ra[AV], rg[GV];
+    // the lane's first row of the slice, formed once: a stage's rows sit at the wave-uniform offsets (row0 - r_begin + 4 u)
+    // * lda from it (scalar arithmetic instead of a 64-bit vector multiply per load)
+    const float *pa0 = A + (r_begin + wave) * lda + 4 * lane;
+    const float *pg0 = G + (r_begin + 2 * wave + g_sub) * ldg + 4 * g_j;
     auto fetch = [&](int64_t row0) {                          // zeros past the slice
+        const int64_t d = row0 - r_begin;                     // wave-uniform
 #pragma unroll
         for (int u = 0; u < AV; ++u) {
             const int64_t row = row0 + wave + 4 * u;
             ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_on && row < r_end) ra[u] = *reinterpret_cast<const float4 *>(A + row * lda + 4 * lane);
+            if (a_on && row < r_end) ra[u] = *reinterpret_cast<const float4 *>(pa0 + (d + 4 * u) * lda);
         }
 #pragma unroll
         for (int u = 0; u < GV; ++u) {
             const int64_t row = row0 + 2 * wave + g_sub + 8 * u;
             rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_on && row < r_end) rg[u] = *reinterpret_cast<const float4 *>(G + row * ldg + 4 * g_j);
+            if (g_on && row < r_end) rg[u] = *reinterpret_cast<const float4 *>(pg0 + (d + 8 * u) * ldg);
         }
     };
     // the fused dropout masks A on its way into LDS: every element is hashed ONCE per workgroup, by the thread that
@@ -769,9 +774,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
             const int p = par + PAR * q;                      // row pair of the stage: rows 2 p, 2 p + 1
             const float gv = lg[2 * p * np_];
             const float *ar = la + 2 * p * kp;
+            // all MT tiles, unconditionally: a run-time `m < mt` test puts a branch in front of every MFMA, and hipcc
+            // then issues read - wait - MFMA one tile at a time (40 % of the wave cycles waiting, profiles/r04_pmc_dense.md)
+            // instead of fetching the pair's fragments together.  Tiles past mt multiply whatever follows in the LDS image
+            // into accumulators nobody reads (MT is the smallest instantiated count >= mt).
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                if (m < mt) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32 * m], gv, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32 * m], gv, acc[m], 0, 0, 0);
         }
     };
     if (r_end > r_begin) {
@@ -1318,7 +1326,8 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
     } while (0)
 #define TGCN_TNS_M(NT, DR)                                                                                            \
     do {                                                                                                              \
-        if (mtg <= 4) TGCN_TNS(NT, 4, DR); else if (mtg <= 7) TGCN_TNS(NT, 7, DR); else TGCN_TNS(NT, 8, DR);         \
+        if (mtg <= 2) TGCN_TNS(NT, 2, DR); else if (mtg <= 4) TGCN_TNS(NT, 4, DR);                                   \
+        else if (mtg <= 7) TGCN_TNS(NT, 7, DR); else TGCN_TNS(NT, 8, DR);                                           \
     } while (0)
                 if (drop) {
                     if (ntg == 1) TGCN_TNS_M(1, true); else if (ntg == 2) TGCN_TNS_M(2, true); else TGCN_TNS_M(4, true);
