@@ -769,17 +769,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
     auto compute = [&](int buf) {
         const float *la = tn_lds + buf * stage_floats + half * kp + c;
         const float *lg = tn_lds + buf * stage_floats + SR * kp + half * np_ + 32 * t + c;
+        // All MT tiles, unconditionally (a run-time `m < mt` test puts a branch in front of every MFMA; tiles past mt
+        // multiply whatever follows in the LDS image into accumulators nobody reads: MT is the smallest instantiated count
+        // >= mt), and the fragments of row pair q + 1 are read while pair q is multiplied: left to itself hipcc issues each
+        // fragment read right in front of the MFMA that needs it, and the wave then waits out the LDS latency once per tile
+        // (40 % of the wave cycles waiting, profiles/r04_pmc_dense.md).
+        constexpr int n_pairs = SR / 2 / PAR;
+        float af[2][MT], gf[2];
 #pragma unroll
-        for (int q = 0; q < SR / 2 / PAR; ++q) {
-            const int p = par + PAR * q;                      // row pair of the stage: rows 2 p, 2 p + 1
-            const float gv = lg[2 * p * np_];
-            const float *ar = la + 2 * p * kp;
-            // all MT tiles, unconditionally: a run-time `m < mt` test puts a branch in front of every MFMA, and hipcc
-            // then issues read - wait - MFMA one tile at a time (40 % of the wave cycles waiting, profiles/r04_pmc_dense.md)
-            // instead of fetching the pair's fragments together.  Tiles past mt multiply whatever follows in the LDS image
-            // into accumulators nobody reads (MT is the smallest instantiated count >= mt).
+        for (int m = 0; m < MT; ++m) af[0][m] = la[2 * par * kp + 32 * m];
+        gf[0] = lg[2 * par * np_];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32 * m], gv, acc[m], 0, 0, 0);
+        for (int q = 0; q < n_pairs; ++q) {
+            if (q + 1 < n_pairs) {
+                const int p = par + PAR * (q + 1);            // row pair of the stage: rows 2 p, 2 p + 1
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[(q + 1) & 1][m] = la[2 * p * kp + 32 * m];
+                gf[(q + 1) & 1] = lg[2 * p * np_];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][m], gf[q & 1], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     if (r_end > r_begin) {
