@@ -619,6 +619,10 @@ def main():
     backend = os.environ.get("TGCN_BENCH_BACKEND", "nccl")
     if "TGCN_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["TGCN_BENCH_DEVICE"])
+        if backend == "nccl" and world > 1:
+            # RCCL ranks on ONE card (rehearsal): each poses as its own host, RCCL joins them over loopback sockets
+            from pytextgcn_amd.sharded import let_rccl_ranks_share_a_device
+            let_rccl_ranks_share_a_device(rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

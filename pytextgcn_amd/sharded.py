@@ -63,6 +63,20 @@ def init_process_group(backend: str = "nccl", device: Optional[torch.device] = N
         dist.init_process_group("nccl", **kw)
 
 
+def let_rccl_ranks_share_a_device(rank: int) -> None:
+    """REHEARSAL aid for a box with fewer GPUs than ranks; call it in every rank BEFORE the process group is made.
+    RCCL refuses two ranks whose (host hash, PCI bus id) agree ("Duplicate GPU detected").  Giving each process its
+    own NCCL_HOSTID makes the ranks look like separate hosts, so the communicator connects them through the socket
+    transport (loopback) instead of P2P / shared memory: a few GB/s, i.e. no statement about speed, but it is RCCL
+    itself with world size > 1 -- the enqueue order of all_gather_into_tensor / reduce_scatter_tensor /
+    all_to_all_single / batched send + recv on the communicator's stream, which gloo (synchronous, host-staged)
+    cannot exercise.  Never used by a real one-rank-per-GPU run."""
+    import os
+    os.environ["NCCL_HOSTID"] = f"tgcn-shared-device-rank-{rank}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
 # --------------------------------------------------------------------------------------------------
 # local-operator engine: the HIP library.  (tests inject a CPU engine built on the oracle to run the
 # partition + exchange logic under gloo without a GPU; the package itself ships no CPU engine.)

@@ -331,6 +331,8 @@ def main(rank, world, port, kinds, errfile, backend="gloo", device="cpu"):
     torch.set_num_threads(2)
     try:
         if device != "cpu":
+            if backend == "nccl" and world > 1 and "{rank}" not in device:
+                sharded.let_rccl_ranks_share_a_device(rank)   # RCCL ranks on ONE card: socket transport
             device = device.format(rank=rank)              # "cuda:{rank}": one GPU per rank
             torch.cuda.set_device(torch.device(device))
         # a bounded timeout: a mismatched collective must fail the test, not hang the box

@@ -1,6 +1,7 @@
 """The sharded product path with the HIP engine on the GPU(s) of the test box: gloo ranks sharing
-cuda:0 (everything but RCCL itself), a single-rank RCCL group (the nccl code path) and, when the box
-has two or more GPUs, a two-rank RCCL group with one rank per GPU.
+cuda:0, a single-rank RCCL group, RCCL groups of 2 / 3 / 4 ranks that SHARE cuda:0 (each rank poses as its own host, so
+RCCL connects them over loopback sockets) and, when the box has two or more GPUs, a two-rank RCCL group with one rank
+per GPU.
 
 The file name sorts last on purpose: these are multi-process tests, and a failure here under
 `pytest -x` must not keep the single-process graph-builder / Text2Graph GPU tests from running."""
@@ -55,9 +56,22 @@ def test_two_rccl_ranks_one_per_gpu(cuda, monkeypatch, exchange):
     (all_to_all_single with split sizes) over xGMI -- and, inside the worker, every form against every other
     (check_exchange_forms).  Needs two GPUs; the one-GPU test box skips it."""
     if _n_gpus() < 2:
-        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+        pytest.skip("needs >= 2 GPUs (the one-GPU form of this test is test_rccl_ranks_sharing_one_gpu)")
     monkeypatch.setenv("TGCN_EXCHANGE", exchange)
     run(2, ["wordoc_big", "wordoc_allhubs"], "nccl", device="cuda:{rank}")
+
+
+@pytest.mark.parametrize("world,exchange,chunks", [(2, "collective", "1"), (2, "p2p", "1"), (2, "halo", "1"),
+                                                   (2, "collective", "4"), (4, "collective", "2"), (3, "halo", "1")])
+def test_rccl_ranks_sharing_one_gpu(cuda, monkeypatch, world, exchange, chunks):
+    """RCCL itself with world size > 1 on a ONE-GPU box: every rank on cuda:0 with its own NCCL_HOSTID, so the
+    communicator joins them over loopback sockets (sharded.let_rccl_ranks_share_a_device).  What gloo cannot show: the
+    collectives are ENQUEUED on RCCL's (high-priority) stream and overlap the local SpMMs, the send / recv pairs are
+    batched groups, reduce_scatter_tensor / all_gather_into_tensor are the native calls.  Same checks as every other
+    backend: the partition against the oracle, every exchange form against every other, the sharded network."""
+    monkeypatch.setenv("TGCN_EXCHANGE", exchange)
+    monkeypatch.setenv("TGCN_RS_CHUNKS", chunks)
+    run(world, ["wordoc_big", "wordoc_allhubs"] if world == 2 else ["wordoc_big"], "nccl")
 
 
 def test_bench_two_ranks_as_a_plain_command(cuda):
@@ -78,3 +92,39 @@ def test_bench_two_ranks_as_a_plain_command(cuda):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["unit"] == "edges/s"
     assert rec["exchange_selection"]["chosen"] in rec["exchange_selection"]["ms_per_step"]
+
+
+def _bench_two_rccl_ranks(cmd_prefix, extra_env=None):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TGCN_BENCH_DEVICE="0", **(extra_env or {}))        # backend: the default, "nccl" = RCCL
+    res = subprocess.run(cmd_prefix + [os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "3",
+                                       "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                         timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["unit"] == "edges/s"
+    assert rec["rccl"]["backend"] == "nccl (RCCL)" and rec["rccl"]["ranks"] == 2
+    assert rec["rccl"]["distinct_devices"] == 1                  # a rehearsal, and the record says so
+    assert rec["rccl"]["high_priority_stream"] is True
+    return rec
+
+
+def test_bench_two_rccl_ranks_sharing_one_gpu_as_a_plain_command(cuda):
+    """`python3 bench.py --gpus 2` over RCCL (not gloo): the parent's budget / fallback machinery, every exchange form
+    in the trial steps (the parent's watchdog covers the pairwise ones), the timed region and the sharded epoch."""
+    rec = _bench_two_rccl_ranks([sys.executable])
+    assert "fallback" not in rec, rec.get("fallback")
+    assert rec["exchange_selection"]["chosen"] in rec["exchange_selection"]["ms_per_step"]
+
+
+def test_bench_two_rccl_ranks_sharing_one_gpu_under_torch_distributed_run(cuda):
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), over RCCL."""
+    rec = _bench_two_rccl_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                 "--master-addr", "127.0.0.1", "--master-port", str(free_port())])
+    assert rec["exchange_selection"]["chosen"].startswith("collective")
