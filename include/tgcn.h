@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 3
+#define TGCN_ABI_VERSION 4
 
 enum {
     TGCN_OK = 0,
@@ -284,7 +284,7 @@ int tgcn_gemm_tn(const float *A, int64_t lda, const float *G, int64_t ldg, float
 
 /* The same products with the inverted dropout of the reference's GCN.forward (textgcn/lib/models.py:23,
  * `x = self.dropout(x)` between the layers) fused in, so that the dropped activation and its mask are
- * never stored: element (r, c) of the masked [N x w] activation is kept iff hash(seed, r * w + c) >=
+ * never stored: element (r, c) of the masked [N x w] activation is kept iff hash(seed, r, c) >=
  * p * 2^32 and scaled by 1 / (1 - p); all three regenerate the same mask from `seed` (8 bytes in DEVICE
  * memory, read by the kernels: safe under HIP-graph capture).
  *   tgcn_gemm_nn_dropout   C = dropout(A) @ B          mask over A [N x k]   (XW = dropout(H) @ W)
@@ -298,6 +298,22 @@ int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ld
 int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                          int64_t N, int k, int n, double p, const uint64_t *seed, void *workspace,
                          size_t workspace_bytes, tgcn_stream stream);
+
+/* The same two products with the keep decisions RECORDED instead of hashed twice: the nn product (forward) writes the mask
+ * of its A operand, 4 bits per lane step, `tgcn_dropout_mask_words(k, n)` 32-bit words per row (the caller allocates
+ * [N x mask_stride] words; 0 = a product of this shape cannot record it -- chunked reductions, the split-bf16 mode -- use the
+ * entry points above); the tn product (weight gradient) reads it back: one load and four bit tests per 16 bytes of A in
+ * place of four hashes.  Bit for bit the results of tgcn_gemm_nn_dropout / tgcn_gemm_tn_dropout with the same seed (the
+ * tn side falls back on the hash wherever its kernel does not take the record; the nt product always hashes: its mask
+ * costs nothing, it sits on the matrix pipe).  Layout: column c of a row is bit 4 ((c / 8) % 8) + (c & 3) of word
+ * ((c / 4) & 1) * (words / 2) + c / 64. */
+size_t tgcn_dropout_mask_words(int k, int n);
+int tgcn_gemm_nn_dropout_mask(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                              int64_t N, int k, int n, double p, const uint64_t *seed, uint32_t *mask,
+                              int64_t mask_stride, tgcn_stream stream);
+int tgcn_gemm_tn_dropout_mask(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                              int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
+                              int64_t mask_stride, void *workspace, size_t workspace_bytes, tgcn_stream stream);
 /* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt / _tn for the
  * shapes of the GCN layers (nn: k = 200, 33 <= n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64,
  * contiguous operands; + the _dropout forms and, for nt, the _colsum form).  Every other shape keeps the fp32 kernels.  on != 0: every fp32 product is

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
 NORM_OFF, NORM_ACCURATE, NORM_REFERENCE = 0, 1, 2          # `normalize` of tgcn_plan_create
@@ -74,6 +74,11 @@ SIGNATURES = {
                                      c_double, c_void_p, c_void_p]),
     "tgcn_gemm_tn_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                      c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tgcn_dropout_mask_words": (c_size_t, [c_int, c_int]),
+    "tgcn_gemm_nn_dropout_mask": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                          c_double, c_void_p, c_void_p, c_int64, c_void_p]),
+    "tgcn_gemm_tn_dropout_mask": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                          c_double, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "tgcn_set_gemm_split": (c_int, [c_int]),
     "tgcn_gemm_nt_colsum_workspace_bytes": (c_size_t, [c_int]),
     "tgcn_gemm_nt_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -61,7 +61,15 @@ struct Drop {
     uint32_t thresh;       // keep iff hash >= thresh;  thresh = p * 2^32
     float scale;           // 1 / (1 - p)
     int ld;                // logical width of the masked matrix
+    uint32_t *bits;        // optional record of the keep decisions (layout: drop_bits_word / _shift below); the nn
+    int64_t bits_stride;   // product writes it, the tn product reads it instead of hashing every element again
 };
+
+// The recorded keep mask of a [N x k] operand: 4 bits per (row, 8-column step q, lane half h) -- the 4 consecutive
+// columns 8 q + 4 h .. + 3 a lane of the nn kernel multiplies in step q -- packed 8 steps to a word; a row holds the
+// words of half 0, then those of half 1 (wph each).  Column c: q = c / 8, h = (c / 4) & 1, bit 4 (q % 8) + (c & 3) of
+// word h * wph + q / 8.
+__host__ __device__ __forceinline__ int drop_bits_wph(int k) { return ((k + 7) / 8 + 7) / 8; }
 
 // The hash is split so that the expensive part is paid once per ROW and lane, not once per element: a row key
 // (murmur3 mixing of the 64-bit row index with the seed) and, per element, key + col * golden-ratio constant
@@ -90,14 +98,18 @@ __device__ __forceinline__ uint32_t drop_row_key_uniform(uint32_t s_lo, uint32_t
 
 __device__ __forceinline__ uint32_t drop_col_term(int col) { return uint32_t(col) * 0x9E3779B1u; }
 
-__device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t col_term, const Drop &d) {
+__device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col_term, const Drop &d) {
     uint32_t h = row_key + col_term;
     h ^= h >> 15;
     h *= 0x2c1b3c6du;
     h ^= h >> 12;
     h *= 0x297a2d39u;
     h ^= h >> 15;
-    return h >= d.thresh ? v * d.scale : 0.f;
+    return h >= d.thresh;
+}
+
+__device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t col_term, const Drop &d) {
+    return drop_keep(row_key, col_term, d) ? v * d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -146,7 +158,12 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
     for (int64_t blk = int64_t(blockIdx.x) * 4 + wave; blk < n_blocks; blk += int64_t(gridDim.x) * 4) {
         const int64_t row = blk * 32 + r;
         uint32_t a_key = 0;                    // dropout on the A operand: one row per lane and block
-        if constexpr (DROP && !TRANS_B) a_key = drop_row_key(s_lo, s_hi, row);
+        uint32_t mword = 0;                    // the keep decisions of up to 8 steps, on their way to drop.bits
+        uint32_t *mrow = nullptr;
+        if constexpr (DROP && !TRANS_B) {
+            a_key = drop_row_key(s_lo, s_hi, row);
+            if (drop.bits) mrow = drop.bits + row * drop.bits_stride + half * drop_bits_wph(k);
+        }
         // rows past the end shadow the last row: loads stay in bounds, their results are not stored
         const float *arow = A + std::min(row, N - 1) * lda + 4 * half;
         f32x16 acc[NT];
@@ -219,8 +236,15 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
                 float av[4] = {a[0], a[1], a[2], a[3]};
                 if constexpr (DROP && !TRANS_B) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-                        av[s4] = drop_elem(av[s4], a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const bool keep = drop_keep(a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
+                        av[s4] = keep ? av[s4] * drop.scale : 0.f;
+                        mword |= keep ? (1u << (4 * (q & 7) + s4)) : 0u;
+                    }
+                    if ((q & 7) == 7 || q + 1 == NQ) {         // a word of the recorded mask is complete
+                        if (drop.bits && row < N) mrow[q >> 3] = mword;
+                        mword = 0;
+                    }
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
@@ -252,8 +276,15 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             float av[4] = {a0.x, a0.y, a0.z, a0.w};
             if constexpr (DROP && !TRANS_B) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    av[s4] = drop_elem(av[s4], a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bool keep = drop_keep(a_key, drop_col_term(p_k0 + 8 * q + 4 * half + s4), drop);
+                    av[s4] = keep ? av[s4] * drop.scale : 0.f;
+                    mword |= keep ? (1u << (4 * (q & 7) + s4)) : 0u;
+                }
+                if ((q & 7) == 7 || q + 1 == nq) {
+                    if (drop.bits && row < N) mrow[q >> 3] = mword;
+                    mword = 0;
+                }
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
@@ -689,7 +720,10 @@ inline size_t tn_staged_lds_bytes(int k, int n) {
     return sizeof(float) * std::max(stage, reduce);
 }
 
-template <int NT, int MT, bool DROP>
+// BITS (with DROP): the keep decisions come from the record the nn product left (Drop::bits) -- one 4-byte load and a few
+// bit tests per float4 instead of four hashes: the hash of an element is vector-ALU work that ADDS to the MFMA time on this
+// part (profiles/r04_pmc_dense.md), 0.18 ms of the 0.76 ms of the masked product at the c4 shapes.
+template <int NT, int MT, bool DROP, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ G, int64_t ldg, int64_t N, int k,
                                                            int n, int64_t rows_per_wg, float *__restrict__ partial,
@@ -725,10 +759,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
     const int g_sub = lane >> 5, g_j = lane & 31;            // G: lanes 0-31 one row, lanes 32-63 the next
     const bool g_on = g_j < n4;
     float4 ra[AV], rg[GV];
+    uint32_t rbw = 0;                                        // BITS: one word of the stage's recorded mask per lane
     // the lane's first row of the slice, formed once: a stage's rows sit at the wave-uniform offsets (row0 - r_begin + 4 u)
     // * lda from it (scalar arithmetic instead of a 64-bit vector multiply per load)
     const float *pa0 = A + (r_begin + wave) * lda + 4 * lane;
     const float *pg0 = G + (r_begin + 2 * wave + g_sub) * ldg + 4 * g_j;
+    // Recorded mask.  The AV = 8 rows a wave copies per stage hold 8 words each (k <= 256): ONE 4-byte load per lane and
+    // stage fetches them all -- lane i word i & 7 of the wave's row i >> 3 -- and the lane that masks the float4 at
+    // columns 4 j .. of row u (step q = j / 2, half j & 1 of that row: word (j & 1) wph + j / 16) takes its word from
+    // lane 8 u + that index (ds_bpermute).  A load per row and lane instead cost 0.07 ms at the c4 shapes: the
+    // instructions, not the bytes.
+    const uint32_t *pb0 = nullptr;
+    const int b_shift = 4 * ((lane >> 1) & 7);
+    int b_src = 0;
+    if constexpr (BITS) {
+        static_assert(!BITS || AV == 8, "one mask word per lane and stage assumes 8 rows per wave");
+        pb0 = drop.bits + (r_begin + wave + 4 * (lane >> 3)) * drop.bits_stride + (lane & 7);
+        b_src = (lane & 1) * drop_bits_wph(k) + (lane >> 4);
+    }
     auto fetch = [&](int64_t row0) {                          // zeros past the slice
         const int64_t d = row0 - r_begin;                     // wave-uniform
 #pragma unroll
@@ -736,6 +784,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
             const int64_t row = row0 + wave + 4 * u;
             ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a_on && row < r_end) ra[u] = *reinterpret_cast<const float4 *>(pa0 + (d + 4 * u) * lda);
+        }
+        if constexpr (BITS) {
+            rbw = 0u;
+            if ((lane & 7) < 2 * drop_bits_wph(k) && row0 + wave + 4 * (lane >> 3) < r_end) rbw = pb0[d * drop.bits_stride];
         }
 #pragma unroll
         for (int u = 0; u < GV; ++u) {
@@ -750,14 +802,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
         float *la = tn_lds + buf * stage_floats, *lg = la + SR * kp;
 #pragma unroll
         for (int u = 0; u < AV; ++u) {
+            int w = 0;                                        // every lane takes part: a lane switched off reads as 0
+            if constexpr (DROP && BITS) w = __shfl(static_cast<int>(rbw), 8 * u + b_src, 64);
             if (a_on) {
                 float4 v = ra[u];
-                if constexpr (DROP) {
+                // (the factor 1 / (1 - p) of the kept elements is applied ONCE, to the k x n result, by k_gemm_tn_reduce:
+                // here an element is kept or zeroed, nothing else)
+                if constexpr (DROP && BITS) {
+                    // a 1-bit signed field extract gives 0 or ~0: two vector instructions per element
+                    v.x = __uint_as_float(__float_as_uint(v.x) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift, 1)));
+                    v.y = __uint_as_float(__float_as_uint(v.y) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift + 1, 1)));
+                    v.z = __uint_as_float(__float_as_uint(v.z) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift + 2, 1)));
+                    v.w = __uint_as_float(__float_as_uint(v.w) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift + 3, 1)));
+                } else if constexpr (DROP) {
                     const uint32_t key = drop_row_key_uniform(s_lo, s_hi, row0 + wave + 4 * u);
-                    v.x = drop_elem(v.x, key, drop_col_term(k0 + 4 * lane), drop);
-                    v.y = drop_elem(v.y, key, drop_col_term(k0 + 4 * lane + 1), drop);
-                    v.z = drop_elem(v.z, key, drop_col_term(k0 + 4 * lane + 2), drop);
-                    v.w = drop_elem(v.w, key, drop_col_term(k0 + 4 * lane + 3), drop);
+                    v.x = drop_keep(key, drop_col_term(k0 + 4 * lane), drop) ? v.x : 0.f;
+                    v.y = drop_keep(key, drop_col_term(k0 + 4 * lane + 1), drop) ? v.y : 0.f;
+                    v.z = drop_keep(key, drop_col_term(k0 + 4 * lane + 2), drop) ? v.z : 0.f;
+                    v.w = drop_keep(key, drop_col_term(k0 + 4 * lane + 3), drop) ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4 *>(la + (wave + 4 * u) * kp + 4 * lane) = v;
             }
@@ -984,9 +1046,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
 
 // C[kk][j] = sum_b partial[b][kk][j], in block order (deterministic); one thread per element,
 // 4-way split over b combined through LDS to shorten the serial chain.
+// `scale`: the dropout factor 1 / (1 - p) of the LDS-staged masked kernel, which only keeps or zeroes (1 otherwise).
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict__ partial, int nb,
                                                         int mpad, int npad, int k, int n,
-                                                        float *__restrict__ C, int64_t ldc) {
+                                                        float *__restrict__ C, int64_t ldc, float scale = 1.0f) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;  // element of the [k][n] result
@@ -1007,7 +1070,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict_
     }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && e < k * n) C[int64_t(kk) * ldc + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && e < k * n) {
+        const float sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        C[int64_t(kk) * ldc + j] = scale == 1.0f ? sum : sum * scale;
+    }
 }
 
 int tn_blocks(int64_t N) {
@@ -1238,6 +1304,32 @@ int tgcn_gemm_nn_dropout(const float *A, int64_t lda, const float *B, int64_t ld
     return gemm_nn_impl("tgcn_gemm_nn_dropout", A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
 }
 
+size_t tgcn_dropout_mask_words(int k, int n) {
+    // recorded by the one-launch fp32 nn product only: the small operand [k x n] must fit the LDS in one piece (the
+    // condition of launch_tall) and the split-bf16 mode must be off (its kernels do not write the record)
+    if (k <= 0 || n <= 0 || tgcn::g_gemm_split.load(std::memory_order_relaxed) != 0) return 0;
+    const size_t kpad = (static_cast<size_t>(k) + 7) & ~size_t(7), npad = 32 * ((static_cast<size_t>(n) + 31) / 32);
+    if (npad > 256 || sizeof(float) * kpad * npad > 160 * 1024) return 0;
+    return 2 * static_cast<size_t>(tgcn::drop_bits_wph(k));
+}
+
+int tgcn_gemm_nn_dropout_mask(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                              int64_t N, int k, int n, double p, const uint64_t *seed, uint32_t *mask,
+                              int64_t mask_stride, tgcn_stream stream) {
+    const char *fn = "tgcn_gemm_nn_dropout_mask";
+    const size_t words = tgcn_dropout_mask_words(k, n);
+    if (!mask || words == 0 || mask_stride < static_cast<int64_t>(words)) {
+        tgcn::set_error("%s: the mask of a [N x %d] operand takes %zu words per row (0: this product cannot record it); "
+                        "mask=%p, stride %lld", fn, k, words, static_cast<void *>(mask), (long long)mask_stride);
+        return TGCN_E_INVALID;
+    }
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop(fn, p, seed, k, d));
+    d.bits = mask;
+    d.bits_stride = mask_stride;
+    return gemm_nn_impl(fn, A, lda, B, ldb, C, ldc, N, k, n, &d, stream);
+}
+
 int tgcn_gemm_nt_dropout(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                          int64_t N, int k, int n, double p, const uint64_t *seed, tgcn_stream stream) {
     tgcn::Drop d{};
@@ -1329,12 +1421,18 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
             if (staged) {
                 const int64_t rpw = ((N + nb - 1) / nb + kTnStageRows - 1) / kTnStageRows * kTnStageRows;
                 const size_t lb = tn_staged_lds_bytes(kg, ng);
+#define TGCN_TNS2(NT, MT_, DR, BI)                                                                                    \
+    do {                                                                                                              \
+        TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_staged<NT, MT_, DR, BI>),       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));       \
+        k_gemm_tn_staged<NT, MT_, DR, BI><<<nb, 256, lb, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rpw, partial,             \
+                                                              drop ? *drop : Drop{}, i0);                           \
+    } while (0)
+                // the recorded mask describes whole rows of A: usable when this launch covers all k columns
+                const bool from_bits = drop && drop->bits && i0 == 0 && kg == k;
 #define TGCN_TNS(NT, MT_, DR)                                                                                         \
     do {                                                                                                              \
-        TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_staged<NT, MT_, DR>),           \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));       \
-        k_gemm_tn_staged<NT, MT_, DR><<<nb, 256, lb, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rpw, partial,                 \
-                                                          drop ? *drop : Drop{}, i0);                               \
+        if (DR && from_bits) TGCN_TNS2(NT, MT_, DR, DR); else TGCN_TNS2(NT, MT_, DR, false);                         \
     } while (0)
 #define TGCN_TNS_M(NT, DR)                                                                                            \
     do {                                                                                                              \
@@ -1348,9 +1446,11 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
                 }
 #undef TGCN_TNS_M
 #undef TGCN_TNS
+#undef TGCN_TNS2
                 TGCN_HIP_CHECK(hipGetLastError());
                 k_gemm_tn_reduce<<<(kg * ng + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mtg, 32 * ntg, kg, ng,
-                                                                     C + int64_t(i0) * ldc + j0, ldc);
+                                                                     C + int64_t(i0) * ldc + j0, ldc,
+                                                                     drop ? drop->scale : 1.0f);
                 TGCN_HIP_CHECK(hipGetLastError());
                 continue;
             }
@@ -1389,6 +1489,22 @@ int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ld
     TGCN_CHECK(make_drop("tgcn_gemm_tn_dropout", p, seed, k, d));
     return gemm_tn_impl("tgcn_gemm_tn_dropout", A, lda, G, ldg, C, ldc, N, k, n, workspace, workspace_bytes, &d,
                         stream);
+}
+
+int tgcn_gemm_tn_dropout_mask(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
+                              int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
+                              int64_t mask_stride, void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+    const char *fn = "tgcn_gemm_tn_dropout_mask";
+    if (!mask || k <= 0 || mask_stride < 2 * static_cast<int64_t>(tgcn::drop_bits_wph(k))) {
+        tgcn::set_error("%s: need the mask tgcn_gemm_nn_dropout_mask recorded for this operand (rows of >= %d words; "
+                        "stride %lld)", fn, k > 0 ? 2 * tgcn::drop_bits_wph(k) : 0, (long long)mask_stride);
+        return TGCN_E_INVALID;
+    }
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop(fn, p, seed, k, d));
+    d.bits = const_cast<uint32_t *>(mask);       // read only on this side
+    d.bits_stride = mask_stride;
+    return gemm_tn_impl(fn, A, lda, G, ldg, C, ldc, N, k, n, workspace, workspace_bytes, &d, stream);
 }
 
 }  // extern "C"

@@ -46,20 +46,30 @@ def _check_seed(seed: Tensor, dev) -> None:
         raise TypeError("dropout seed must be a one-element int64 tensor on the operand's device")
 
 
-def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
-    """a [N, k] @ b [k, n]; with `seed`: dropout(a, p) @ b, the mask regenerated from the seed."""
+def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_mask: bool = False):
+    """a [N, k] @ b [k, n]; with `seed`: dropout(a, p) @ b, the mask regenerated from the seed.
+    `record_mask` (with `seed`): returns (product, mask) where `mask` is the kernel's record of its keep decisions
+    ([N, words] int32, `tgcn_gemm_nn_dropout_mask`) for `gemm_tn(..., mask=...)`, or None when a product of this shape
+    cannot record it."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(1)
     c = alloc_padded(N, n, a.device)          # rows of 4 j floats (zero pad columns): the propagate step takes it as it is
     args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
+    mask = None
     if seed is None:
         _lib.check(lib.tgcn_gemm_nn(*args, _stream_ptr(a.device)))
     else:
         _check_seed(seed, a.device)
-        _lib.check(lib.tgcn_gemm_nn_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
-    return c
+        words = int(lib.tgcn_dropout_mask_words(k, n)) if record_mask else 0
+        if words:
+            mask = torch.empty(N, words, dtype=torch.int32, device=a.device)
+            _lib.check(lib.tgcn_gemm_nn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                     _stream_ptr(a.device)))
+        else:
+            _lib.check(lib.tgcn_gemm_nn_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
+    return (c, mask) if record_mask else c
 
 
 def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_colsums: bool = False) -> Tensor:
@@ -91,8 +101,9 @@ def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_cols
     return c
 
 
-def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor:
-    """a[N, k]^T @ g[N, n]; with `seed`: dropout(a, p)^T @ g."""
+def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None, mask: Tensor = None) -> Tensor:
+    """a[N, k]^T @ g[N, n]; with `seed`: dropout(a, p)^T @ g; `mask`: the record `gemm_nn(..., record_mask=True)` left
+    of the same dropout (same bits as hashing from the seed, without the hashing)."""
     lib = _lib.load()
     if a.stride(1) != 1:
         a = a.contiguous()
@@ -108,8 +119,15 @@ def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None) -> Tensor
         _lib.check(lib.tgcn_gemm_tn(*args, ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
     else:
         _check_seed(seed, a.device)
-        _lib.check(lib.tgcn_gemm_tn_dropout(*args, float(p), seed.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            _stream_ptr(a.device)))
+        if mask is not None:
+            if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
+                    mask.stride(1) != 1:
+                raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
+            _lib.check(lib.tgcn_gemm_tn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                     ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
+        else:
+            _lib.check(lib.tgcn_gemm_tn_dropout(*args, float(p), seed.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                _stream_ptr(a.device)))
     return c
 
 
@@ -128,19 +146,28 @@ class _XW(torch.autograd.Function):
 
 
 class _XWDropout(torch.autograd.Function):
-    """dropout(x, p) @ w with the mask regenerated in all three GEMMs (never stored)."""
+    """dropout(x, p) @ w with the mask a stateless hash of (seed, row, column) in all three GEMMs: the dropped
+    activation is never stored.  The forward product leaves its keep decisions as 4 bytes per 32 elements (1 / 32 of
+    x) when a weight gradient will be wanted; dropout(x)^T @ g then tests bits instead of hashing every element a
+    second time -- the same decisions, so the same bits in the result."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, p: float, seed: Tensor):
-        ctx.save_for_backward(x, w, seed)
         ctx.p = p
-        return gemm_nn(x.detach(), w.detach(), p, seed)
+        if ctx.needs_input_grad[1]:
+            out, mask = gemm_nn(x.detach(), w.detach(), p, seed, record_mask=True)
+        else:
+            out, mask = gemm_nn(x.detach(), w.detach(), p, seed), None
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(x, w, seed, *([mask] if mask is not None else []))
+        return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, w, seed = ctx.saved_tensors
+        x, w, seed = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
         dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
-        dw = gemm_tn(x, g, ctx.p, seed) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
+        dw = gemm_tn(x, g, ctx.p, seed, mask) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
         return dx, dw, None, None
 
 

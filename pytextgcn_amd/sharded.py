@@ -125,7 +125,7 @@ class HipEngine:
 
     def xw_dropout(self, x: Tensor, w: Tensor, p: float) -> Tensor:
         from . import dense
-        return dense.xw_dropout(x, w, p)      # dropout fused into the three GEMMs (mask never stored)
+        return dense.xw_dropout(x, w, p)      # dropout fused into the three GEMMs (dropped activation never stored)
 
     def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int, return_pred: bool = False):
         from .functional import masked_cross_entropy

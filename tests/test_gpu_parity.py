@@ -1944,6 +1944,66 @@ def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
     assert float(dense.gemm_nn(x, w, 1.0, seed).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,h,C,p", [(100_003, 200, 64, 0.5), (4097, 100, 20, 0.7), (333, 36, 8, 0.2), (65, 64, 64, 0.5),
+                                     (1, 8, 4, 0.5), (5000, 256, 128, 0.3)])
+def test_recorded_dropout_mask_equals_the_hashed_one(cuda, N, h, C, p):
+    """tgcn_gemm_nn_dropout_mask leaves its keep decisions as bits (layout documented in include/tgcn.h) and
+    tgcn_gemm_tn_dropout_mask reads them back: the record IS the hash's mask (every bit, decoded here), the forward
+    product is unchanged and the weight gradient comes out bit for bit the hashed kernel's."""
+    from pytextgcn_amd import _lib, dense
+    gen = torch.Generator(device=cuda).manual_seed(N * 7 + h)
+    seed = torch.randint(-2**62, 2**62, (1,), device=cuda, generator=gen)
+    x = torch.randn(N, h, device=cuda, generator=gen)
+    w = torch.randn(h, C, device=cuda, generator=gen)
+    g = torch.randn(N, C, device=cuda, generator=gen)
+    words = int(_lib.load().tgcn_dropout_mask_words(h, C))
+    assert words == 2 * (((h + 7) // 8 + 7) // 8)
+    out, mask = dense.gemm_nn(x, w, p, seed, record_mask=True)
+    assert mask is not None and tuple(mask.shape) == (N, words) and mask.dtype == torch.int32
+    assert torch.equal(out, dense.gemm_nn(x, w, p, seed))
+    keep = _drop_mask(N, h, p, seed, cuda)
+    c = torch.arange(h, device=cuda)
+    word = ((c // 4) & 1) * (words // 2) + c // 64
+    bit = 4 * ((c // 8) % 8) + (c & 3)
+    decoded = ((mask.long() & 0xFFFFFFFF)[:, word] >> bit) & 1
+    assert torch.equal(decoded.bool(), keep)
+    dw_hash = dense.gemm_tn(x, g, p, seed)
+    dw_bits = dense.gemm_tn(x, g, p, seed, mask)
+    assert torch.equal(dw_bits, dw_hash)
+    # the autograd wrapper records the mask only when a weight gradient is wanted, and gives the same gradients either way
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    dense.xw_dropout(xr, wr, p, seed).backward(g)
+    assert torch.equal(wr.grad, dw_hash)
+    assert torch.equal(xr.grad, dense.gemm_nt(g, w, p, seed))
+    xr2 = x.clone().requires_grad_()
+    dense.xw_dropout(xr2, w, p, seed).backward(g)              # no weight gradient: nothing recorded
+    assert torch.equal(xr2.grad, xr.grad)
+
+
+def test_recorded_dropout_mask_is_refused_where_it_cannot_be_recorded(cuda):
+    """Chunked reductions (k beyond one LDS image) and the split-bf16 mode do not record: the query says 0 words and
+    the wrapper falls back on the hashed kernels; the C entry point refuses."""
+    from pytextgcn_amd import _lib, dense
+    lib = _lib.load()
+    assert lib.tgcn_dropout_mask_words(1000, 64) == 0 and lib.tgcn_dropout_mask_words(0, 4) == 0
+    seed = dense.new_seed(cuda)
+    x = torch.randn(300, 1000, device=cuda)
+    w = torch.randn(1000, 64, device=cuda)
+    out, mask = dense.gemm_nn(x, w, 0.5, seed, record_mask=True)
+    assert mask is None and torch.equal(out, dense.gemm_nn(x, w, 0.5, seed))
+    bits = torch.zeros(300, 64, dtype=torch.int32, device=cuda)
+    c = torch.empty(300, 64, device=cuda)
+    with pytest.raises(ValueError):
+        _lib.check(lib.tgcn_gemm_nn_dropout_mask(x.data_ptr(), 1000, w.data_ptr(), 64, c.data_ptr(), 64, 300, 1000, 64, 0.5,
+                                                 seed.data_ptr(), bits.data_ptr(), 64, None))
+    prev = dense.enable_split_gemms(True)
+    try:
+        assert lib.tgcn_dropout_mask_words(200, 64) == 0
+    finally:
+        dense.enable_split_gemms(prev)
+    assert lib.tgcn_dropout_mask_words(200, 64) == 8
+
+
 def test_fused_dropout_mask_is_the_documented_hash(cuda):
     """The mask the kernels draw equals the numpy restatement of the hash that tests/test_host.py checks
     statistically (same seed, every element): the two tests pin the same function."""

@@ -25,6 +25,10 @@ cases = {
     "tn": lambda: dense.gemm_tn(H, G),
     "tn_dropout": lambda: dense.gemm_tn(H, G, 0.5, seed),
 }
+if hasattr(dense.gemm_nn, "__kwdefaults__") and "record_mask" in dense.gemm_nn.__code__.co_varnames:
+    _, MASK = dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
+    cases["nn_dropout_record"] = lambda: dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
+    cases["tn_dropout_from_record"] = lambda: dense.gemm_tn(H, G, 0.5, seed, MASK)
 times = {k: [] for k in cases}
 for rnd in range(6):
     for name, fn in cases.items():
