@@ -753,17 +753,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
     // global -> registers -> LDS.  A: wave w copies rows w, w + 4, ... of the stage, lane j the j-th float4 of the row
     // (k / 4 <= 64 of them); G: 16 lanes per row... generally n / 4 <= 32 float4s per row, two rows per wave pass.
-    constexpr int AV = SR / 4, GV = SR / 8;
+    // G rows per load instruction of a wave: n <= 64 (NT <= 2) needs 16 lanes per row, so four rows ride in one
+    // instruction instead of two (half the lanes idle) -- the count of memory instructions is what a stage pays for
+    constexpr int GL = NT <= 2 ? 16 : 32, GR = 64 / GL;
+    constexpr int AV = SR / 4, GV = SR / (4 * GR);
     const int k4 = k >> 2, n4 = n >> 2;
     const bool a_on = lane < k4;
-    const int g_sub = lane >> 5, g_j = lane & 31;            // G: lanes 0-31 one row, lanes 32-63 the next
+    const int g_sub = lane / GL, g_j = lane % GL;            // G: GL lanes per row, GR rows per instruction
     const bool g_on = g_j < n4;
     float4 ra[AV], rg[GV];
     uint32_t rbw = 0;                                        // BITS: one word of the stage's recorded mask per lane
     // the lane's first row of the slice, formed once: a stage's rows sit at the wave-uniform offsets (row0 - r_begin + 4 u)
     // * lda from it (scalar arithmetic instead of a 64-bit vector multiply per load)
     const float *pa0 = A + (r_begin + wave) * lda + 4 * lane;
-    const float *pg0 = G + (r_begin + 2 * wave + g_sub) * ldg + 4 * g_j;
+    const float *pg0 = G + (r_begin + GR * wave + g_sub) * ldg + 4 * g_j;
     // Recorded mask.  The AV = 8 rows a wave copies per stage hold 8 words each (k <= 256): ONE 4-byte load per lane and
     // stage fetches them all -- lane i word i & 7 of the wave's row i >> 3 -- and the lane that masks the float4 at
     // columns 4 j .. of row u (step q = j / 2, half j & 1 of that row: word (j & 1) wph + j / 16) takes its word from
@@ -791,9 +794,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
         }
 #pragma unroll
         for (int u = 0; u < GV; ++u) {
-            const int64_t row = row0 + 2 * wave + g_sub + 8 * u;
+            const int64_t row = row0 + GR * wave + g_sub + 4 * GR * u;
             rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_on && row < r_end) rg[u] = *reinterpret_cast<const float4 *>(pg0 + (d + 8 * u) * ldg);
+            if (g_on && row < r_end) rg[u] = *reinterpret_cast<const float4 *>(pg0 + (d + 4 * GR * u) * ldg);
         }
     };
     // the fused dropout masks A on its way into LDS: every element is hashed ONCE per workgroup, by the thread that
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
         }
 #pragma unroll
         for (int u = 0; u < GV; ++u)
-            if (g_on) *reinterpret_cast<float4 *>(lg + (2 * wave + g_sub + 8 * u) * np_ + 4 * g_j) = rg[u];
+            if (g_on) *reinterpret_cast<float4 *>(lg + (GR * wave + g_sub + 4 * GR * u) * np_ + 4 * g_j) = rg[u];
     };
     auto compute = [&](int buf) {
         const float *la = tn_lds + buf * stage_floats + half * kp + c;
