@@ -1946,11 +1946,13 @@ def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
 
 @pytest.mark.parametrize("N,h,C,p", [(100_003, 200, 64, 0.5), (4097, 100, 20, 0.7), (333, 36, 8, 0.2), (65, 64, 64, 0.5),
                                      (1, 8, 4, 0.5), (5000, 256, 128, 0.3)])
-def test_recorded_dropout_mask_equals_the_hashed_one(cuda, N, h, C, p):
+def test_recorded_dropout_mask_equals_the_hashed_one(cuda, request, N, h, C, p):
     """tgcn_gemm_nn_dropout_mask leaves its keep decisions as bits (layout documented in include/tgcn.h) and
     tgcn_gemm_tn_dropout_mask reads them back: the record IS the hash's mask (every bit, decoded here), the forward
     product is unchanged and the weight gradient comes out bit for bit the hashed kernel's."""
     from pytextgcn_amd import _lib, dense
+    before = dense.enable_split_gemms(False)                   # the fp32 kernels are the ones that record
+    request.addfinalizer(lambda: dense.enable_split_gemms(before))
     gen = torch.Generator(device=cuda).manual_seed(N * 7 + h)
     seed = torch.randint(-2**62, 2**62, (1,), device=cuda, generator=gen)
     x = torch.randn(N, h, device=cuda, generator=gen)
@@ -1980,11 +1982,13 @@ def test_recorded_dropout_mask_equals_the_hashed_one(cuda, N, h, C, p):
     assert torch.equal(xr2.grad, xr.grad)
 
 
-def test_recorded_dropout_mask_is_refused_where_it_cannot_be_recorded(cuda):
+def test_recorded_dropout_mask_is_refused_where_it_cannot_be_recorded(cuda, request):
     """Chunked reductions (k beyond one LDS image) and the split-bf16 mode do not record: the query says 0 words and
     the wrapper falls back on the hashed kernels; the C entry point refuses."""
     from pytextgcn_amd import _lib, dense
     lib = _lib.load()
+    before = dense.enable_split_gemms(False)
+    request.addfinalizer(lambda: dense.enable_split_gemms(before))
     assert lib.tgcn_dropout_mask_words(1000, 64) == 0 and lib.tgcn_dropout_mask_words(0, 4) == 0
     seed = dense.new_seed(cuda)
     x = torch.randn(300, 1000, device=cuda)
