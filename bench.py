@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
+    p.add_argument("--no-verify", action="store_true",
+                   help="N > 1: skip the comparison of the distributed SpMM pair with the single-device plan")
     p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 32)
     p.add_argument("--cpu-ref", choices=["auto", "full", "sample"], default="auto",
                    help="CPU-ref baseline on the full operator (needs ~100 GB of host memory at c4), on a row sample, "
@@ -104,7 +106,7 @@ def launch_ranks(args) -> int:
     The measurement must not be lost to a form of the exchange that hangs or dies on this node: the child gets a wall
     budget (TGCN_BENCH_BUDGET_S, default 420 s).  If it exceeds it, exits non-zero or prints no record, its process group
     is ended and a FRESH child runs the plainest configuration -- RCCL's own collectives, A_r in one piece, no trial
-    steps, no epoch (TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch; budget TGCN_BENCH_FALLBACK_BUDGET_S, default
+    steps, no epoch, no parity check (TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch --no-verify; budget TGCN_BENCH_FALLBACK_BUDGET_S, default
     300 s) -- and its record is relayed with a `"fallback"` field saying why.  Under torch.distributed.run (WORLD_SIZE
     set) this function is not reached."""
     import socket
@@ -134,12 +136,13 @@ def launch_ranks(args) -> int:
     reason = (f"first attempt exceeded its budget of {budget:.0f} s" if rc is None else
               f"first attempt exited with code {rc}" if rc != 0 else "first attempt printed no record")
     print(f"bench.py: {reason} after {time.time() - t0:.0f} s; running the plain configuration "
-          "(TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch)", file=sys.stderr, flush=True)
+          "(TGCN_EXCHANGE=collective TGCN_RS_CHUNKS=1 --no-epoch --no-verify)", file=sys.stderr, flush=True)
     if os.environ.get("TGCN_BENCH_NO_FALLBACK") == "1":
         return rc if rc else 1
     env2 = dict(env, TGCN_EXCHANGE="collective", TGCN_RS_CHUNKS="1")
     env2.pop("TGCN_BENCH_TEST_FAIL", None)               # (the test hook below applies to the first attempt only)
-    rc2, text2 = _run_ranks(command([] if "--no-epoch" in sys.argv else ["--no-epoch"]), env2,
+    plain = [f for f in ("--no-epoch", "--no-verify") if f not in sys.argv]     # nothing but the measurement itself
+    rc2, text2 = _run_ranks(command(plain), env2,
                             float(os.environ.get("TGCN_BENCH_FALLBACK_BUDGET_S", "300")))
     record = _last_record(text2)
     if rc2 == 0 and record is not None:
@@ -201,6 +204,46 @@ def rccl_info(dist, backend, world, rank, local_rank, dev):
     return {"backend": {"nccl": "nccl (RCCL)"}.get(backend, backend) if dist is not None else None, "ranks": world,
             "distinct_devices": len({(d["pci_bus_id"], d["uuid"]) for d in info}),
             "high_priority_stream": hi, "devices": info}
+
+
+def distributed_parity(sg, g, N, F, x_local, gout_local, bias, dev, dist):
+    """The timed distributed SpMM pair against the SINGLE-DEVICE plan of the same graph, inside the same run: every rank
+    builds the whole-graph plan (the graph is on every rank), gathers the operands, and compares ITS rows of `M @ X + b`
+    and `M^T @ G` -- so a scaling record carries the evidence that all N ranks computed what one GPU computes (the sums
+    associate differently over ranks: max-norm relative error, tolerance 1e-5, not bits).  Collective; never raises: a
+    failure is reported in the record (every rank takes the same branches: decisions are all-reduced)."""
+    from pytextgcn_amd.plan import GraphPlan
+
+    def agree(ok):
+        f = torch.tensor([1.0 if ok else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=sg.group)
+        return f.item() > 0
+    t0 = time.perf_counter()
+    need = 4 * N * F * 4 + 24 * (g.edge_index.size(1) + N) * 2        # two operands, two results, a plan with M^T
+    free = torch.cuda.mem_get_info(dev)[0]
+    if not agree(free > 1.5 * need):
+        return {"skipped": f"needs about {need / 1e9:.1f} GB free per device"}
+    out = {"tolerance": 1e-5, "against": "single-device GraphPlan of the same edge list, built in this run on every rank"}
+    try:
+        errs = []
+        plan = GraphPlan(g.edge_index, g.edge_attr, N)
+        for name, loc, b, tr in (("forward", x_local, bias, False), ("transposed", gout_local, None, True)):
+            full = sg.gather_rows(loc)                                   # collective
+            ref = sg.scatter_rows(plan.spmm(full, b, transpose=tr))
+            mine = sg.spmm(loc, b, transpose=tr)                         # collective
+            scale = float(ref.abs().max().item()) or 1.0
+            e = float((mine[sg.real] - ref[sg.real]).abs().max().item()) / scale if bool(sg.real.any()) else 0.0
+            t = torch.tensor([e], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sg.group)
+            out[f"max_rel_err_{name}"] = t.item()
+            errs.append(t.item())
+            del full, ref, mine
+        out["ok"] = bool(max(errs) < 1e-5)
+        out["rows_checked"] = N
+    except Exception as e:                 # noqa: BLE001 - reported, not raised: the measurement stands
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
 
 
 def cpu_model():
@@ -809,6 +852,10 @@ def main():
     # the step contains collectives every rank must enter)
     hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
 
+    parity = None
+    if parallelism != "single" and not args.no_verify:
+        parity = distributed_parity(sg, g, N, F, x, gout, bias, dev, dist)     # collective: every rank takes part
+
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
@@ -936,6 +983,7 @@ def main():
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
             "exchange_selection": exchange_selection,
+            "distributed_parity": parity,
             "rccl": rccl,
             "setup_s": setup_s,
         }

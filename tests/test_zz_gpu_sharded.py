@@ -92,6 +92,8 @@ def test_bench_two_ranks_as_a_plain_command(cuda):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["unit"] == "edges/s"
     assert rec["exchange_selection"]["chosen"] in rec["exchange_selection"]["ms_per_step"]
+    par = rec["distributed_parity"]               # the timed pair against the single-device plan, inside the same run
+    assert par["ok"] is True and par["max_rel_err_forward"] < 1e-5 and par["max_rel_err_transposed"] < 1e-5, par
 
 
 def _bench_two_rccl_ranks(cmd_prefix, extra_env=None):
@@ -111,6 +113,7 @@ def _bench_two_rccl_ranks(cmd_prefix, extra_env=None):
     assert rec["rccl"]["backend"] == "nccl (RCCL)" and rec["rccl"]["ranks"] == 2
     assert rec["rccl"]["distinct_devices"] == 1                  # a rehearsal, and the record says so
     assert rec["rccl"]["high_priority_stream"] is True
+    assert rec["distributed_parity"]["ok"] is True, rec["distributed_parity"]
     return rec
 
 

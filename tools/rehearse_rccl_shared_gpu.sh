@@ -21,5 +21,6 @@ d = json.load(open("$R/bench_${cfg}_rccl${n}.json"))
 print({k: d.get(k) for k in ("n_gpus", "value", "ms_per_step", "sharded_epoch_ms", "setup_s")})
 print(d["rccl"]["backend"], d["rccl"]["ranks"], "distinct devices", d["rccl"]["distinct_devices"], "high priority", d["rccl"]["high_priority_stream"])
 print(d.get("exchange_selection"))
+print("parity vs the single-device plan:", d.get("distributed_parity"))
 PY
 done
