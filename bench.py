@@ -399,8 +399,10 @@ def fabric_traffic(config, n_gpus):
             rec = json.load(f).get(f"{config}_n{n_gpus}", {})
         if "bytes_per_launch" in rec:
             fresh = rec.get("kernel_sha16") == spmm_kernel_sha16()
-            return (rec["bytes_per_launch"], f"profiles/traffic.json[{config}_n{n_gpus}] ({rec.get('round', '?')})",
-                    fresh)
+            src = f"profiles/traffic.json[{config}_n{n_gpus}] ({rec.get('round', '?')})"
+            if n_gpus > 1:        # N > 1: the counters of ONE rank's local operators, taken on one GPU (tools/prof_local_step.py)
+                src += ": rank 0's local operators of this partition measured on one GPU; the exchange's bytes are not in it"
+            return rec["bytes_per_launch"], src, fresh
     except (OSError, ValueError):
         pass
     return None, None, False
