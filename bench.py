@@ -531,7 +531,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     return sorted(times)[len(times) // 2]
 
 
-def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
+def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
     summed with one all-reduce; predictions of the owned rows go to the host."""
@@ -550,6 +550,10 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False):
     with torch.no_grad():
         model.weights[0].uniform_(-0.0017, 0.0017)            # glorot bound of an N x h matrix
     opt = pkg.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
+    if fuse_w1:
+        # the regular rows of the rank's W1 shard are updated inside the backward SpMM, the hub slice after its
+        # reduce-scatter (ShardedGraph.spmm_adam_w1): no [n_local, h] gradient, no optimizer pass over those rows
+        opt.fuse_into_backward(model.weights[0])
     times = []
     for rep in range(reps + 1):
         dist.barrier()
@@ -863,6 +867,8 @@ def main():
         del x, gout
         epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
         epoch_ms_reuse = sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True)
+        epoch_ms_w1 = sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True)
+        epoch_ms_w1_reuse = sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True)
     diagnostics = exchange_diagnostics(sg, F, dev, dist) if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout

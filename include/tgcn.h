@@ -190,6 +190,15 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
                    double beta1, double beta2, double eps, double weight_decay, int64_t step,
                    const float *scalars_dev, void *workspace, size_t workspace_bytes, tgcn_stream stream);
 
+/* tgcn_spmm_adam_split -- tgcn_spmm_adam whose gathered operand lives in two buffers, as tgcn_spmm_split's does: rows
+ * [0, split) in G, rows [split, n_cols) in G2.  For the 1-D partition's backward SpMM: the regular rows of a rank's W1
+ * shard are updated inside the launch that computes their gradient from the gathered hub block and the rank's own rows.
+ * G2 = NULL is tgcn_spmm_adam. */
+int tgcn_spmm_adam_split(const tgcn_plan *plan, int transpose, const float *G, int64_t ldg, const float *G2, int64_t ldg2,
+                         int64_t split, int F, float *param, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                         int64_t ldp, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                         const float *scalars_dev, void *workspace, size_t workspace_bytes, tgcn_stream stream);
+
 /* Row movement of the multi-GPU exchange (pytextgcn_amd/sharded.py; nothing in the reference corresponds: it is
  * single-device, flat_amazon.py:84-86).  Row-major fp32 rows, int64 row indices on the device, enqueue only.
  *   tgcn_rows_gather          out[i, :]    = x[idx[i], :]     (pack the hub rows a peer references)

@@ -45,6 +45,9 @@ SIGNATURES = {
     "tgcn_spmm_adam": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "tgcn_spmm_adam_split": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double, c_int64,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_rows_gather": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "tgcn_rows_scatter": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),
     "tgcn_rows_reduce_ranked": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64,

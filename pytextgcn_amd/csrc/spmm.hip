@@ -654,9 +654,14 @@ int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
 }
 
 // the SpMM whose rows feed the optimizer (tgcn_spmm_adam); float4 path only, checked by the caller
-int launch_spmm_adam(const CsrBlock &b, const float *X, int64_t ldx, int F, float *carry, hipStream_t stream,
-                     const AdamRow &ad) {
-    return launch_vec<4>(b, X, ldx, X, ldx, INT32_MAX, F, nullptr, nullptr, 0, carry, stream, &ad);
+int launch_spmm_adam(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split, int F,
+                     float *carry, hipStream_t stream, const AdamRow &ad) {
+    if (X2 == nullptr) {  // single operand
+        X2 = X;
+        ldx2 = ldx;
+        split = INT32_MAX;
+    }
+    return launch_vec<4>(b, X, ldx, X2, ldx2, split, F, nullptr, nullptr, 0, carry, stream, &ad);
 }
 
 }  // namespace tgcn
@@ -667,6 +672,14 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
                    float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, int64_t ldp, double lr, double beta1,
                    double beta2, double eps, double weight_decay, int64_t step, const float *scalars_dev,
                    void *workspace, size_t workspace_bytes, tgcn_stream stream) {
+    return tgcn_spmm_adam_split(plan, transpose, G, ldg, nullptr, 0, 0, F, param, exp_avg, exp_avg_sq, max_exp_avg_sq, ldp,
+                                lr, beta1, beta2, eps, weight_decay, step, scalars_dev, workspace, workspace_bytes, stream);
+}
+
+int tgcn_spmm_adam_split(const tgcn_plan *plan, int transpose, const float *G, int64_t ldg, const float *G2, int64_t ldg2,
+                         int64_t split, int F, float *param, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                         int64_t ldp, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                         const float *scalars_dev, void *workspace, size_t workspace_bytes, tgcn_stream stream) {
     using namespace tgcn;
     if (!plan || !G || !param || !exp_avg || !exp_avg_sq) {
         set_error("tgcn_spmm_adam: NULL plan / G / param / state");
@@ -675,6 +688,10 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
     if (F <= 0 || F % 4 != 0 || ldg < F || ldp < F || ldg % 4 != 0 || ldp % 4 != 0 || (step < 1 && !scalars_dev)) {
         set_error("tgcn_spmm_adam: need F %% 4 == 0, ldg, ldp >= F and multiples of 4, step >= 1 (F=%d ldg=%lld ldp=%lld)",
                   F, (long long)ldg, (long long)ldp);
+        return TGCN_E_INVALID;
+    }
+    if (G2 && (ldg2 < F || ldg2 % 4 != 0 || split < 0 || split >= INT32_MAX || reinterpret_cast<uintptr_t>(G2) % 16 != 0)) {
+        set_error("tgcn_spmm_adam_split: need ldg2 >= F and a multiple of 4, 0 <= split < 2^31, G2 16-byte aligned");
         return TGCN_E_INVALID;
     }
     const uintptr_t a = reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(param) |
@@ -715,8 +732,8 @@ int tgcn_spmm_adam(const tgcn_plan *plan, int transpose, const float *G, int64_t
     int cur = -1;
     TGCN_HIP_CHECK(hipGetDevice(&cur));
     if (cur != plan->device) TGCN_HIP_CHECK(hipSetDevice(plan->device));
-    const int rc = launch_spmm_adam(b, G, ldg, F, need ? static_cast<float *>(workspace) : nullptr,
-                                    static_cast<hipStream_t>(stream), ad);
+    const int rc = launch_spmm_adam(b, G, ldg, G2, ldg2, static_cast<int>(split), F,
+                                    need ? static_cast<float *>(workspace) : nullptr, static_cast<hipStream_t>(stream), ad);
     if (cur != plan->device) (void)hipSetDevice(cur);
     return rc;
 }

@@ -100,6 +100,44 @@ class Adam(Optimizer):
         return True
 
     @torch.no_grad()
+    def _fused_update_sharded(self, p, sg, g) -> bool:
+        """The same for a rank's row shard of W1 in the 1-D partition (pytextgcn_amd.sharded._ShardedPropagate): the
+        regular rows are updated inside the backward SpMM (split operand), the hub slice by one Adam pass once its
+        gradient rows are reduced.  False = not applicable (caller takes the plain path)."""
+        group = next((gr for gr in self.param_groups if any(p is q for q in gr["params"])), None)
+        if group is None or group.get("capturable", False) or not p.is_cuda or p.dtype != torch.float32 \
+                or not p.is_contiguous() or p.dim() != 2 or p.size(1) % 4 != 0 or p.size(1) <= 128 \
+                or g.stride(1) != 1 or g.stride(0) % 4 != 0 or not hasattr(sg, "spmm_adam_w1") \
+                or not hasattr(sg.dirs[0].B, "export_csr"):
+            return False
+        lib = _lib.load()
+        st, _ = self._state_of(p, group)
+        if st.get("fused_pending", False):
+            raise RuntimeError(
+                "pytextgcn_amd.optim.Adam: a parameter registered with fuse_into_backward() received a second backward "
+                "before step(): its update would be applied twice.")
+        st["fused_pending"] = True
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        vmax = st.get("max_exp_avg_sq")
+        hyper = (group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
+
+        def adam(rows, grad, op, g1, g2):
+            pr, m, v = p[rows], st["exp_avg"][rows], st["exp_avg_sq"][rows]
+            vm = vmax[rows] if vmax is not None else None
+            if pr.numel() == 0:
+                return
+            if op is not None:                 # rows whose gradient is the operator's product: spent inside the launch
+                op.spmm_adam(g1, pr, m, v, vm, *hyper, transpose=False, g2=g2)
+            else:
+                _lib.check(lib.tgcn_adam_step(pr.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                              vm.data_ptr() if vm is not None else None, pr.numel(), *hyper,
+                                              _stream_ptr(p.device)))
+        sg.spmm_adam_w1(g, adam)
+        torch.autograd.graph.increment_version(p)
+        return True
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

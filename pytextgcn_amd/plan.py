@@ -231,21 +231,27 @@ class GraphPlan:
 
 def _spmm_adam(self, g: Tensor, param: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, max_exp_avg_sq: Optional[Tensor],
                lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
-               scalars: Optional[Tensor] = None, transpose: bool = True) -> None:
-    """param <- Adam(param, grad = M(^T) @ g) row by row, the gradient never stored (`tgcn_spmm_adam`)."""
+               scalars: Optional[Tensor] = None, transpose: bool = True, g2: Optional[Tensor] = None) -> None:
+    """param <- Adam(param, grad = M(^T) @ g) row by row, the gradient never stored (`tgcn_spmm_adam`).  `g2`: the
+    operand's rows from g.size(0) on (a split operand, as GraphPlan.spmm's x2: `tgcn_spmm_adam_split`)."""
     _require_cuda(g, "g")
     F = g.size(1)
     n_out = self.n_rows_t if transpose else self.n_rows
     need = self.n_cols_t if transpose else self.n_cols
-    ok = (g.dtype == torch.float32 and g.dim() == 2 and g.size(0) == need and g.stride(1) == 1
+    have = g.size(0) + (g2.size(0) if g2 is not None else 0)
+    ok = (g.dtype == torch.float32 and g.dim() == 2 and have == need and g.stride(1) == 1
           and param.shape == (n_out, F) and param.is_contiguous() and param.dtype == torch.float32)
+    if g2 is not None:
+        ok = ok and (g2.dtype == torch.float32 and g2.dim() == 2 and g2.size(1) == F and g2.stride(1) == 1
+                     and g2.device == g.device)
     for t in (exp_avg, exp_avg_sq, max_exp_avg_sq):
         ok = ok and (t is None or (t.shape == param.shape and t.is_contiguous() and t.dtype == torch.float32))
     if not ok:
         raise ValueError("spmm_adam: operand / parameter / state shapes do not fit the operator")
     ws = self._workspace(int(transpose), F, g.device)
-    _lib.check(self._lib.tgcn_spmm_adam(
-        self._h, int(transpose), g.data_ptr(), g.stride(0), F, param.data_ptr(), exp_avg.data_ptr(),
+    _lib.check(self._lib.tgcn_spmm_adam_split(
+        self._h, int(transpose), g.data_ptr(), g.stride(0), g2.data_ptr() if g2 is not None else None,
+        g2.stride(0) if g2 is not None else 0, g.size(0) if g2 is not None else 0, F, param.data_ptr(), exp_avg.data_ptr(),
         exp_avg_sq.data_ptr(), max_exp_avg_sq.data_ptr() if max_exp_avg_sq is not None else None, param.stride(0),
         lr, beta1, beta2, eps, weight_decay, int(step), scalars.data_ptr() if scalars is not None else None,
         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_ptr(g.device)))

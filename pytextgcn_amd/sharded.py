@@ -299,6 +299,7 @@ class _Direction:
     def __init__(self):
         self.A_entries = None          # (row = owner * hp + slot, col, w) of A_r, kept to cut row chunks
         self.B = None
+        self.B_hub = self.B_reg = None # B_r cut at row hp (spmm_adam_w1: the regular rows' sums feed the optimizer)
         self.chunks = {}               # K -> [_Chunk] (K = 1: the whole A_r)
         self.need_cols = None          # halo: gathered-block rows (owner * hp + slot) B_r references, sorted
         self.need_counts = None        #       ... how many of them every rank owns
@@ -855,6 +856,57 @@ class ShardedGraph:
             y[:hp] += rs_out
         return y
 
+    # ---- the backward SpMM of layer 1 with the optimizer inside (one-hot features: d W1 = M^T d H1) ------------
+    def _split_B(self, d: _Direction) -> None:
+        """B_r as two operators, cut at local row hp: the hub slice (its sums still wait for the other ranks'
+        partial rows) and the regular rows (final as they leave the kernel, so `tgcn_spmm_adam_split` can spend them
+        on the optimizer).  Built once, from B_r's own CSR: same entries, same order within a row."""
+        if d.B_reg is not None or d.B_hub is not None:
+            return
+        if not hasattr(d.B, "export_csr"):
+            raise RuntimeError("the fused W1 update needs the HIP engine's operators")
+        hp, rp, W = self.hp, self.rp, self.world
+        rowptr, col, val = d.B.export_csr()
+        counts = (rowptr[1:] - rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(hp + rp, device=col.device), counts)
+        cut = int(rowptr[hp].item())
+        col = col.long()
+        if hp > 0:
+            d.B_hub = self.engine.make_op(row[:cut], col[:cut], val[:cut], hp, W * hp + rp)
+        if rp > 0:
+            d.B_reg = self.engine.make_op(row[cut:] - hp, col[cut:], val[cut:], rp, W * hp + rp)
+
+    def spmm_adam_w1(self, g_local: Tensor, adam) -> None:
+        """W1_local <- Adam(W1_local, M^T @ g) with the regular rows' update INSIDE the SpMM that computes their gradient
+        (`GraphPlan.spmm_adam`, split operand: gathered hub block | own rows) -- the [rp, F] gradient and the optimizer's
+        pass over those rows disappear, as `optim.Adam.fuse_into_backward` does on one device.  The hub slice takes the
+        plain road: its gradient rows are complete only after the reduce-scatter, then one Adam pass over hp rows.
+        `adam(rows, grad_or_None, op, g1, g2)` is the optimizer's closure (pytextgcn_amd.optim.Adam._fused_update_sharded).
+        The exchange is the one of `spmm(..., transpose=True)`: same collectives, same order on every rank."""
+        d = self.dirs[1 if not self.symmetric else 0]
+        hp, rp = self.hp, self.rp
+        if g_local.shape[0] != self.n_local:
+            raise ValueError(f"operand has {g_local.shape[0]} rows, this rank owns {self.n_local}")
+        if g_local.size(1) <= self._NARROW:
+            raise ValueError("spmm_adam_w1 serves the wide (hidden) width only")
+        self._split_B(d)
+        g_local = g_local.contiguous()
+        xbuf, gathered = self._start_gather(d, g_local)
+        pending = []
+        if d.A is not None:
+            xr = g_local[hp:]
+            for ch in d.chunks[self.rs_chunks]:
+                pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
+        gathered()
+        own = g_local[hp:] if rp > 0 else None
+        y_hub = d.B_hub.spmm(xbuf, None, x2=own) if d.B_hub is not None else None
+        if d.B_reg is not None:
+            adam(slice(hp, hp + rp), None, d.B_reg, xbuf, own)        # overlaps the reduce-scatter
+        if y_hub is not None:
+            for finish in pending:
+                finish(y_hub)
+            adam(slice(0, hp), y_hub, None, None, None)
+
     def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):
         """All-gather as W - 1 direct sends and receives per rank, batched into one group call.  Only for
         transfers the backend orders on the stream (`_stream_ordered`)."""
@@ -924,18 +976,33 @@ class ShardedGraph:
             off += n
 
 
+def _fused_optimizer_for(param):
+    from .optim import fused_optimizer_for
+    return fused_optimizer_for(param)
+
+
 class _ShardedPropagate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor]):
         ctx.sg = sg
         ctx.has_bias = bias is not None
+        # the operand IS the rank's W1 shard and its optimizer asked for the update inside this backward
+        # (pytextgcn_amd.optim.Adam.fuse_into_backward): see ShardedGraph.spmm_adam_w1
+        ctx.fused_param = xw_local if (isinstance(xw_local, nn.Parameter)
+                                       and _fused_optimizer_for(xw_local) is not None) else None
         return sg.spmm(xw_local.detach(), None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         sg = ctx.sg
         g = grad_out.contiguous()
-        d_xw = sg.spmm(g, None, transpose=True) if ctx.needs_input_grad[1] else None
+        d_xw = None
+        if ctx.needs_input_grad[1]:
+            p = getattr(ctx, "fused_param", None)
+            opt = _fused_optimizer_for(p) if p is not None else None
+            # every rank takes the same branch: the registration and the shapes are the same on all of them
+            if opt is None or not opt._fused_update_sharded(p, sg, g):
+                d_xw = sg.spmm(g, None, transpose=True)
         d_bias = sg.colsum_real(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return None, d_xw, d_bias
 
@@ -948,6 +1015,8 @@ class _ShardedPropagateCached(torch.autograd.Function):
     def forward(ctx, sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor], value: Tensor):
         ctx.sg = sg
         ctx.has_bias = bias is not None
+        ctx.fused_param = xw_local if (isinstance(xw_local, nn.Parameter)
+                                       and _fused_optimizer_for(xw_local) is not None) else None
         return value.detach()
 
     @staticmethod

@@ -323,6 +323,56 @@ def check_hip(kind, g, hubs, N, dev):
     assert rel_err(mine.weights[1].grad.cpu(), ref.layers[1].weight.grad) < 5e-5
     for i in (0, 1):
         assert rel_err(mine.biases[i].grad.cpu(), ref.layers[i].bias.grad) < 5e-5, i
+    check_fused_w1(sg, gd, N, dev, F)
+
+
+def check_fused_w1(sg, gd, N, dev, F=200):
+    """optim.Adam.fuse_into_backward on the rank's W1 shard: three training steps with the update of the regular rows
+    inside the backward SpMM (split operand) and the hub slice after its reduce-scatter, against the same three steps
+    with backward + step.  The two roads sum a row's products in the same kernels' orders up to the cut of B_r at row hp
+    (each part picks its own work partition), so: a tight tolerance, not bits.  Also: the first layer's weight gets no
+    .grad, a second backward before step() raises, every exchange form serves."""
+    import pytextgcn_amd as pkg
+    torch.manual_seed(11)
+    init = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0).state_dict()
+    y_l, m_l = sg.scatter_rows(gd.y), sg.scatter_rows(gd.train_mask)
+
+    def run(fused, steps=3):
+        model = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
+        model.load_full_state_dict(init)
+        opt = pkg.optim.Adam(model.parameters(), lr=0.02, amsgrad=True)
+        if fused:
+            opt.fuse_into_backward(model.weights[0])
+        losses = []
+        for _ in range(steps):
+            loss = sharded.sharded_cross_entropy(sg, model(), y_l, m_l)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if fused:
+                assert model.weights[0].grad is None
+            model.sync_grads()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return model, opt, torch.stack(losses)
+    plain, _, l_plain = run(False)
+    fused, opt_f, l_fused = run(True)
+    assert sg.dirs[0].B_reg is not None or sg.rp == 0
+    assert torch.allclose(l_fused, l_plain, rtol=1e-5, atol=1e-8), (l_fused, l_plain)
+    for a, b in zip(fused.parameters(), plain.parameters()):
+        assert rel_err(a.detach().cpu(), b.detach().cpu()) < 2e-5, rel_err(a.detach().cpu(), b.detach().cpu())
+    st_f, st_p = opt_f.state[fused.weights[0]], None
+    assert st_f["step"] == 3 and float(st_f["exp_avg"].abs().max()) > 0
+    # a second backward before step() would apply the update twice: refused
+    loss = sharded.sharded_cross_entropy(sg, fused(), y_l, m_l)
+    loss.backward()
+    loss2 = sharded.sharded_cross_entropy(sg, fused(), y_l, m_l)
+    try:
+        loss2.backward()
+        raise AssertionError("second backward before step() was accepted")
+    except RuntimeError as e:
+        assert "second backward" in str(e)
+    fused.sync_grads()
+    opt_f.step()
 
 
 def main(rank, world, port, kinds, errfile, backend="gloo", device="cpu"):
