@@ -26,6 +26,9 @@ p.add_argument("--docs", type=int, default=20000)
 p.add_argument("--epochs", type=int, default=30)
 p.add_argument("--backend", default="nccl")
 p.add_argument("--device", type=int, default=None, help="force a device index (several ranks on one GPU: gloo only)")
+p.add_argument("--hidden", type=int, default=100, help="hidden width (flat_amazon.py:26 uses 100)")
+p.add_argument("--fuse-w1", action="store_true",
+               help="update this rank's W1 rows inside the backward SpMM (optim.Adam.fuse_into_backward; takes hidden > 128)")
 args = p.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -58,13 +61,15 @@ for t in (coo, attr, labels, masks):
     dist.broadcast(t, 0)
 
 sg = ShardedGraph(coo.t(), attr, N, hubs=th.arange(N, device=dev) < V)
-gcn = ShardedGCN(sg, N, n_classes, n_hidden_gcn=100, dropout=dropout).to(dev)
+gcn = ShardedGCN(sg, N, n_classes, n_hidden_gcn=args.hidden, dropout=dropout).to(dev)
 with th.no_grad():                                  # glorot over the FULL (N, h) matrix
-    a = (6.0 / (N + 100)) ** 0.5
+    a = (6.0 / (N + args.hidden)) ** 0.5
     gcn.weights[0].uniform_(-a, a).mul_(sg.real.unsqueeze(1))
 y_l = sg.scatter_rows(labels)
 train_l, val_l, test_l = (sg.scatter_rows(masks[i].bool()) for i in range(3))
 optimizer = optim.Adam(gcn.parameters(), lr=lr, amsgrad=True)
+if args.fuse_w1:
+    optimizer.fuse_into_backward(gcn.weights[0])    # same steps, no [n_local, h] gradient, no optimizer pass over W1's regular rows
 
 
 def accuracy(logits, mask):
