@@ -313,8 +313,7 @@ int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ld
  * [N x mask_stride] words; 0 = a product of this shape cannot record it -- chunked reductions, the split-bf16 mode -- use the
  * entry points above); the tn product (weight gradient) reads it back: one load and four bit tests per 16 bytes of A in
  * place of four hashes.  Bit for bit the results of tgcn_gemm_nn_dropout / tgcn_gemm_tn_dropout with the same seed (the
- * tn side falls back on the hash wherever its kernel does not take the record; the nt product always hashes: its mask
- * costs nothing, it sits on the matrix pipe).  Layout: column c of a row is bit 4 ((c / 8) % 8) + (c & 3) of word
+ * tn side falls back on the hash wherever its kernel does not take the record).  Layout: column c of a row is bit 4 ((c / 8) % 8) + (c & 3) of word
  * ((c / 4) & 1) * (words / 2) + c / 64. */
 size_t tgcn_dropout_mask_words(int k, int n);
 int tgcn_gemm_nn_dropout_mask(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
@@ -323,6 +322,13 @@ int tgcn_gemm_nn_dropout_mask(const float *A, int64_t lda, const float *B, int64
 int tgcn_gemm_tn_dropout_mask(const float *A, int64_t lda, const float *G, int64_t ldg, float *C, int64_t ldc,
                               int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
                               int64_t mask_stride, void *workspace, size_t workspace_bytes, tgcn_stream stream);
+/* ... and the input-gradient product with the column sums, its mask (over the [N x n] RESULT: the same matrix the forward
+ * product masked) read from that record instead of hashed: bit for bit tgcn_gemm_nt_colsum with the same seed (the kernel
+ * falls back on the hash for shapes whose record it does not take). */
+int tgcn_gemm_nt_colsum_mask(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                             int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
+                             int64_t mask_stride, float *colsum, void *workspace, size_t workspace_bytes,
+                             tgcn_stream stream);
 /* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt / _tn for the
  * shapes of the GCN layers (nn: k = 200, 33 <= n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64,
  * contiguous operands; + the _dropout forms and, for nt, the _colsum form).  Every other shape keeps the fp32 kernels.  on != 0: every fp32 product is

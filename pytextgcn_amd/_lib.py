@@ -82,6 +82,8 @@ SIGNATURES = {
                                           c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "tgcn_gemm_tn_dropout_mask": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                           c_double, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_gemm_nt_colsum_mask": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                         c_double, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_set_gemm_split": (c_int, [c_int]),
     "tgcn_gemm_nt_colsum_workspace_bytes": (c_size_t, [c_int]),
     "tgcn_gemm_nt_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -121,7 +121,9 @@ __device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t c
 // COLSUM: the workgroup also leaves the column sums of the rows of C it wrote (after the mask) in
 // colpart[blockIdx.x][0..n) -- for the nt product that is the bias gradient of the layer whose output the
 // product differentiates (db1 = column sums of dH1), taken from the accumulators instead of a second pass over C.
-template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP, bool COLSUM = false>
+// BITS (nt with DROP): the mask on the result comes from the record the forward product left (Drop::bits) instead of 16 NT
+// hashes per lane and block -- see the epilogue.
+template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP, bool COLSUM = false, bool BITS = false>
 __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGCN_TALL_MIN_BLOCKS : 1) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
@@ -163,6 +165,13 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
         if constexpr (DROP && !TRANS_B) {
             a_key = drop_row_key(s_lo, s_hi, row);
             if (drop.bits) mrow = drop.bits + row * drop.bits_stride + half * drop_bits_wph(k);
+        }
+        // BITS: this block's slice of the recorded mask, 32 rows x 8 words = 1 KB: lane l fetches the 4 words of half l & 1
+        // of row l / 2 now (one 16-byte load, in flight under the MFMAs) and parks them in the wave's LDS slice in the epilogue
+        uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (BITS) {
+            const int64_t mrow_ = blk * 32 + (lane >> 1);
+            if (mrow_ < N) mq = *reinterpret_cast<const uint4 *>(drop.bits + mrow_ * drop.bits_stride + 4 * (lane & 1));
         }
         // rows past the end shadow the last row: loads stay in bounds, their results are not stored
         const float *arow = A + std::min(row, N - 1) * lda + 4 * half;
@@ -299,6 +308,55 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             a1 = a2;
             a2 = a3;
         }
+        }
+        if constexpr (BITS) {
+            // The mask of the result from the record: column c = 32 t + r of a row is bit 16 (t & 1) + 4 (r / 8) + (r & 3) of
+            // word t / 2 of half (r / 4) & 1 of that row (drop_bits_wph).  An element costs a 4-byte LDS read, a multiply, a
+            // 1-bit signed field extract and an AND -- where the hash costs ~14 vector instructions.
+            uint32_t *mw = reinterpret_cast<uint32_t *>(lds + ((k + 7) & ~7) * npad + (COLSUM ? 4 * npad : 0)) + wave * 256;
+            *reinterpret_cast<uint4 *>(mw + 4 * lane) = mq;
+            __builtin_amdgcn_wave_barrier();             // the slice belongs to this wave: its LDS operations run in order
+            const int lane_bit = 4 * (r >> 3) + (r & 3);
+            const uint32_t *mlane = mw + 4 * ((r >> 2) & 1);
+            const int64_t row0b = blk * 32 + 4 * half;
+            float *crowb = C + row0b * ldc + r;
+            const bool whole_b = blk * 32 + 32 <= N;
+            // Tiles outer, rows inner -- the order of the unmasked epilogue: consecutive stores of a wave go to DIFFERENT rows.
+            // (Rows outer, with one 16-byte LDS read per row for all tiles, measured 0.09 ms slower before any masking
+            // arithmetic: seven consecutive 128-byte pieces of one row queue up on the same channel.)  The word of (row,
+            // t / 2) is a 4-byte LDS read at a constant offset from the lane's base.
+            const uint32_t *mrow = mlane + 32 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 32 * t + r;
+                if (col < n) {
+                    const int bit = lane_bit + 16 * (t & 1);
+                    if (whole_b) {                       // wave-uniform: only the last block of the matrix is ragged
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ro = (i & 3) + 8 * (i >> 2);
+                            const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mrow[8 * ro + (t >> 1)]), bit, 1));
+                            const float out = __uint_as_float(__float_as_uint(acc[t][i] * drop.scale) & keep);
+                            crowb[int64_t(ro) * ldc + 32 * t] = out;
+                            if constexpr (COLSUM) csum[t] += out;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ro = (i & 3) + 8 * (i >> 2);
+                            const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mrow[8 * ro + (t >> 1)]), bit, 1));
+                            const float out = __uint_as_float(__float_as_uint(acc[t][i] * drop.scale) & keep);
+                            if (row0b + ro < N) {
+                                crowb[int64_t(ro) * ldc + 32 * t] = out;
+                                if constexpr (COLSUM) csum[t] += out;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one tile at a time
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         // C[(i&3) + 8*(i>>2) + 4*half][32 t + r]
         uint32_t c_key[16];                    // dropout on the result: the lane's 16 rows, shared by all tiles
@@ -1093,7 +1151,7 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
                     const Place place) {
     const int nt = (n + 31) / 32;
     const int kpad = (k + 7) & ~7;
-    const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(kpad) * (32 * nt) + (COLSUM ? 4 * 32 * nt : 0));
+    size_t lds_bytes = sizeof(float) * (static_cast<size_t>(kpad) * (32 * nt) + (COLSUM ? 4 * 32 * nt : 0));
     int grid_used = 0;
     if (lds_bytes > 160 * 1024 || nt > 8) {
         set_error("tgcn_gemm: the small operand (%d x %d) does not fit the 160 KB LDS", k, n);
@@ -1117,9 +1175,10 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
             if (v > 0) n_cu = v;
         }
     }
-#define TGCN_TALL_K(NT, K8, NQ_)                                                                     \
+#define TGCN_TALL_K(NT, K8, NQ_) TGCN_TALL_KB(NT, K8, NQ_, false)
+#define TGCN_TALL_KB(NT, K8, NQ_, BI)                                                                \
     do {                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM>); \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM, BI>); \
         TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                            static_cast<int>(lds_bytes)));                         \
         int per_cu = 1;                                                                           \
@@ -1128,8 +1187,8 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
         const int grid = static_cast<int>(std::max<int64_t>(                                      \
             1, std::min<int64_t>({(n_blocks + 3) / 4, int64_t(n_cu) * per_cu, int64_t(kTallMaxGrid)}))); \
         grid_used = grid;                                                                         \
-        k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
-                                                                                     drop, colpart, place); \
+        k_gemm_tall<NT, TRANS_B, K8, NQ_, DROP, COLSUM, BI><<<grid, 256, lds_bytes, s>>>(A, lda, B, ldb, C, ldc, N, k, n, \
+                                                                                         drop, colpart, place); \
     } while (0)
 #define TGCN_TALL(NT)                                                                             \
     do {                                                                                          \
@@ -1168,13 +1227,35 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
         }
 #undef TGCN_SPLIT
     }
-    if (whole && !TRANS_B && k == 200 && nt == 2) {
-        TGCN_TALL_K(2, true, 25);
-        return finish();
+    // ONE resident workgroup per CU for the two GCN shapes when nothing is hashed: measured at c4 (tools/ab_dense.py), with
+    // a second workgroup kept off the CU by reserving more than half of its LDS -- nt 0.67 -> 0.59 ms, nt + column sums
+    // 0.72 -> 0.58, nn 0.55 -> 0.52 (2 per CU: 0.525; its default is 3); the kernels that hash a mask want their second /
+    // third workgroup (nt + mask 0.74 -> 0.75, nn + mask 0.60 -> 0.69) and keep it -- and so does the nt product that reads
+    // its mask from the record: its epilogue still works on every element (an LDS read, a multiply, two bit operations:
+    // 0.12 ms when nothing overlaps it), which a second workgroup hides.
+    constexpr size_t kOnePerCu = 82 * 1024;
+    if constexpr (!TRANS_B) {
+        if (whole && k == 200 && nt == 2) {
+            if constexpr (!DROP) lds_bytes = std::max(lds_bytes, kOnePerCu);
+            TGCN_TALL_K(2, true, 25);
+            return finish();
+        }
     }
-    if (whole && TRANS_B && k == 64 && nt == 7) {
+    if constexpr (TRANS_B) {
+    if (whole && k == 64 && nt == 7) {
+        if constexpr (DROP) {
+            // the mask from the forward product's record: n in (192, 256] has four words per row half (16-byte reads)
+            if (drop.bits && n > 192 && drop.bits_stride % 4 == 0 && reinterpret_cast<uintptr_t>(drop.bits) % 16 == 0) {
+                lds_bytes += 4 * 1024;                  // the waves' mask slices; two workgroups per CU (one: 0.71 ms, two: 0.68)
+                TGCN_TALL_KB(7, true, 8, true);
+                return finish();
+            }
+        } else {
+            lds_bytes = std::max(lds_bytes, kOnePerCu);
+        }
         TGCN_TALL_K(7, true, 8);
         return finish();
+    }
     }
     switch (nt) {
         case 1: TGCN_TALL(1); break;
@@ -1188,6 +1269,7 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
     }
 #undef TGCN_TALL
 #undef TGCN_TALL_K
+#undef TGCN_TALL_KB
     return finish();
 }
 
@@ -1360,6 +1442,28 @@ int tgcn_gemm_nt_colsum(const float *A, int64_t lda, const float *B, int64_t ldb
     tgcn::Drop d{};
     TGCN_CHECK(make_drop(fn, p, seed, n, d));
     return gemm_nt_impl(fn, A, lda, B, ldb, C, ldc, N, k, n, &d, stream, colsum, colpart);
+}
+
+int tgcn_gemm_nt_colsum_mask(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                             int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
+                             int64_t mask_stride, float *colsum, void *workspace, size_t workspace_bytes,
+                             tgcn_stream stream) {
+    const char *fn = "tgcn_gemm_nt_colsum_mask";
+    if (!colsum || n <= 0 || !workspace || workspace_bytes < tgcn_gemm_nt_colsum_workspace_bytes(n)) {
+        tgcn::set_error("%s: colsum and a workspace of %zu bytes are required (%zu given)", fn,
+                        tgcn_gemm_nt_colsum_workspace_bytes(n), workspace_bytes);
+        return colsum && n > 0 ? TGCN_E_WORKSPACE : TGCN_E_INVALID;
+    }
+    if (!mask || !seed || mask_stride < 2 * static_cast<int64_t>(tgcn::drop_bits_wph(n))) {
+        tgcn::set_error("%s: need the seed and the mask tgcn_gemm_nn_dropout_mask recorded for the [N x %d] operand (rows of "
+                        ">= %d words; stride %lld)", fn, n, 2 * tgcn::drop_bits_wph(n), (long long)mask_stride);
+        return TGCN_E_INVALID;
+    }
+    tgcn::Drop d{};
+    TGCN_CHECK(make_drop(fn, p, seed, n, d));
+    d.bits = const_cast<uint32_t *>(mask);       // read only on this side
+    d.bits_stride = mask_stride;
+    return gemm_nt_impl(fn, A, lda, B, ldb, C, ldc, N, k, n, &d, stream, colsum, static_cast<float *>(workspace));
 }
 
 size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {

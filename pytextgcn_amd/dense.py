@@ -72,10 +72,12 @@ def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_ma
     return (c, mask) if record_mask else c
 
 
-def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_colsums: bool = False) -> Tensor:
+def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_colsums: bool = False,
+            mask: Tensor = None) -> Tensor:
     """a [N, k] @ b[n, k]^T; with `seed` the [N, n] result is masked and scaled (dropout backward).
     `note_colsums`: the kernel also sums the columns of the result it stores and the sums are recorded for
-    `plan.colsum` (the result is a gradient on its way to a layer with a bias)."""
+    `plan.colsum` (the result is a gradient on its way to a layer with a bias).  `mask` (with `seed` and `note_colsums`):
+    the record `gemm_nn(..., record_mask=True)` left of the same dropout -- same bits, no hashing."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
@@ -89,8 +91,15 @@ def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_cols
         sums = torch.empty(n, dtype=torch.float32, device=a.device)
         ws_bytes = lib.tgcn_gemm_nt_colsum_workspace_bytes(n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-        _lib.check(lib.tgcn_gemm_nt_colsum(*args, float(p), seed.data_ptr() if seed is not None else None,
-                                           sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
+        if mask is not None and seed is not None:
+            if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
+                    mask.stride(1) != 1:
+                raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
+            _lib.check(lib.tgcn_gemm_nt_colsum_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                    sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
+        else:
+            _lib.check(lib.tgcn_gemm_nt_colsum(*args, float(p), seed.data_ptr() if seed is not None else None,
+                                               sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
         note_colsum(c, sums)
         return c
     if seed is None:
@@ -154,7 +163,7 @@ class _XWDropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, p: float, seed: Tensor):
         ctx.p = p
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             out, mask = gemm_nn(x.detach(), w.detach(), p, seed, record_mask=True)
         else:
             out, mask = gemm_nn(x.detach(), w.detach(), p, seed), None
@@ -166,7 +175,7 @@ class _XWDropout(torch.autograd.Function):
     def backward(ctx, g: Tensor):
         x, w, seed = ctx.saved_tensors[:3]
         mask = ctx.saved_tensors[3] if ctx.has_mask else None
-        dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
+        dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True, mask=mask) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
         dw = gemm_tn(x, g, ctx.p, seed, mask) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
         return dx, dw, None, None
 

@@ -1972,6 +1972,14 @@ def test_recorded_dropout_mask_equals_the_hashed_one(cuda, request, N, h, C, p):
     dw_hash = dense.gemm_tn(x, g, p, seed)
     dw_bits = dense.gemm_tn(x, g, p, seed, mask)
     assert torch.equal(dw_bits, dw_hash)
+    # the input gradient with its column sums, mask from the record: bit for bit the hashed kernel's, sums included
+    from pytextgcn_amd.plan import colsum
+    dx_hash = dense.gemm_nt(g, w, p, seed, note_colsums=True)
+    s_hash = colsum(dx_hash).clone()
+    dx_bits = dense.gemm_nt(g, w, p, seed, note_colsums=True, mask=mask)
+    assert torch.equal(dx_bits, dx_hash)
+    # (the column sums add the same rows in workgroup order, and the two kernels run different grids: rounding, not bits)
+    assert rel_err(colsum(dx_bits), s_hash) < 1e-5
     # the autograd wrapper records the mask only when a weight gradient is wanted, and gives the same gradients either way
     xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
     dense.xw_dropout(xr, wr, p, seed).backward(g)

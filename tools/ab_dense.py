@@ -29,6 +29,8 @@ if hasattr(dense.gemm_nn, "__kwdefaults__") and "record_mask" in dense.gemm_nn._
     _, MASK = dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
     cases["nn_dropout_record"] = lambda: dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
     cases["tn_dropout_from_record"] = lambda: dense.gemm_tn(H, G, 0.5, seed, MASK)
+    if "mask" in dense.gemm_nt.__code__.co_varnames:
+        cases["nt_dropout_colsum_from_record"] = lambda: dense.gemm_nt(G, W, 0.5, seed, note_colsums=True, mask=MASK)
 times = {k: [] for k in cases}
 for rnd in range(6):
     for name, fn in cases.items():
