@@ -53,6 +53,8 @@ def parse():
                    help="CPU-ref baseline on the full operator (needs ~100 GB of host memory at c4), on a row sample, "
                         "or full when MemAvailable allows it (default)")
     p.add_argument("--no-hbm-activity", action="store_true", help="skip the live memory-controller measurement")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="N = 1: do not measure the counter traffic in child runs under rocprofv3 (use profiles/traffic.json)")
     p.add_argument("--launch-check", action="store_true",
                    help="rendezvous only: every rank joins the group, rank 0 prints {launch_check, n_gpus}; no GPU work")
     return p.parse_args()
@@ -406,6 +408,58 @@ def fabric_traffic(config, n_gpus):
     except (OSError, ValueError):
         pass
     return None, None, False
+
+
+def live_fabric_traffic(config, timeout_s=150):
+    """The counter traffic of THIS library on THIS box, measured inside the run: two short child runs of this very bench
+    command (3 steps, no epoch, no CPU legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, only
+    --kernel-trace beside them, the program itself after `--`), summarised exactly as profiles/summarize.py summarises the
+    committed passes: per tgcn_spmm launch = sum over its kernels of the mean (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024.
+    Returns (bytes, note) or (None, reason); never raises, bounded by `timeout_s` per pass.  N = 1 only, rank 0, outside
+    every timed region."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    means = {}
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tgcn_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+               "--no-epoch", "--no-hbm-activity", "--no-live-traffic"]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 timeout=timeout_s)
+            if res.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with {res.returncode}: {res.stderr.decode()[-200:]}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr} left no counter file"
+            per = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] == ctr and "k_spmm" in r["Kernel_Name"]:
+                        name = r["Kernel_Name"].split("k_spmm_", 1)[1].split("<")[0].split("(")[0]
+                        per.setdefault(name, []).append(float(r["Counter_Value"]))
+            if not per:
+                return None, f"no k_spmm_* dispatch in the {ctr} pass"
+            means[ctr] = {k: sum(v) / len(v) for k, v in per.items()}
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            return None, f"{type(e).__name__} in the {ctr} pass: {e}"[:240]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    kernels = sorted(set(means["FETCH_SIZE"]) | set(means["WRITE_SIZE"]))
+    total = sum(2.0 * means["FETCH_SIZE"].get(k, 0.0) + means["WRITE_SIZE"].get(k, 0.0) for k in kernels) * 1024.0
+    note = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over two child runs of this bench command on this "
+            f"box (3 steps each, {time.perf_counter() - t0:.0f} s); per tgcn_spmm launch = sum over its kernels "
+            f"({', '.join('k_spmm_' + k for k in kernels)}) of the mean (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024")
+    return total, note
 
 
 def profile_constant(key):
@@ -896,6 +950,14 @@ def main():
         n_out = N if parallelism == "single" else sg.n_local
         compulsory = 8 * plan.nnz + 4 * n_out + 8 * n_out * F if parallelism == "single" else None
         fabric, fabric_src, fabric_fresh = fabric_traffic(args.config, world)
+        committed = {"bytes_per_launch": fabric, "source": fabric_src, "collected_on_these_kernel_sources": fabric_fresh}
+        live_note = None
+        if parallelism == "single" and not args.no_live_traffic and not args.no_hbm_activity:
+            # the counters of THIS run's library on THIS box (two short child runs under rocprofv3), so that `traffic` is
+            # not a constant the builder committed; the committed figure stays in the record beside it
+            live, live_note = live_fabric_traffic(args.config)
+            if live is not None:
+                fabric, fabric_src, fabric_fresh = live, live_note, True
         hbm_bytes = None
         if hbm and "bytes_per_step" in hbm:
             hbm_bytes = hbm["bytes_per_step"] / 2.0            # a step is two launches (forward, transposed)
@@ -944,6 +1006,7 @@ def main():
             "fabric_gather_ceiling_GBps": FABRIC_GATHER_CEILING_GBPS,
             "frac_fabric_of_gather_ceiling": None if ach_fabric is None else ach_fabric / FABRIC_GATHER_CEILING_GBPS,
             "traffic_fabric": fabric, "traffic_fabric_source": fabric_src, "traffic_fabric_fresh": fabric_fresh,
+            "traffic_fabric_committed": committed, "traffic_fabric_live_note": live_note,
             "compulsory_bytes_per_launch": compulsory,
             "frac_compulsory": None if compulsory is None else compulsory * per_s / HBM_PEAK_GBPS,
             "l2_resident_ceiling_ms": profile_constant(f"{args.config}_F{F}_l2_resident_ceiling_ms"),
