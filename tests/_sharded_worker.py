@@ -360,7 +360,7 @@ def check_fused_w1(sg, gd, N, dev, F=200):
     assert torch.allclose(l_fused, l_plain, rtol=1e-5, atol=1e-8), (l_fused, l_plain)
     for a, b in zip(fused.parameters(), plain.parameters()):
         assert rel_err(a.detach().cpu(), b.detach().cpu()) < 2e-5, rel_err(a.detach().cpu(), b.detach().cpu())
-    st_f, st_p = opt_f.state[fused.weights[0]], None
+    st_f = opt_f.state[fused.weights[0]]
     assert st_f["step"] == 3 and float(st_f["exp_avg"].abs().max()) > 0
     # a second backward before step() would apply the update twice: refused
     loss = sharded.sharded_cross_entropy(sg, fused(), y_l, m_l)
