@@ -1233,7 +1233,12 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
     // third workgroup (nt + mask 0.74 -> 0.75, nn + mask 0.60 -> 0.69) and keep it -- and so does the nt product that reads
     // its mask from the record: its epilogue still works on every element (an LDS read, a multiply, two bit operations:
     // 0.12 ms when nothing overlaps it), which a second workgroup hides.
-    constexpr size_t kOnePerCu = 82 * 1024;
+    // TGCN_TALL_ONE_PER_CU=0 (diagnostic, read once): let as many workgroups onto a CU as fit, as before round 4
+    static const bool one_per_cu = [] {
+        const char *e = std::getenv("TGCN_TALL_ONE_PER_CU");
+        return !(e && e[0] == '0');
+    }();
+    const size_t kOnePerCu = one_per_cu ? 82 * 1024 : 0;
     if constexpr (!TRANS_B) {
         if (whole && k == 200 && nt == 2) {
             if constexpr (!DROP) lds_bytes = std::max(lds_bytes, kOnePerCu);

@@ -16,6 +16,6 @@ SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INS
 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
 SETS
 cd $root
-python tools/summarize_pmc.py $R gemm > $R/dense_pmc.md
+python tools/summarize_pmc.py $R gemm > $R/dense_pmc.md   # (TGCN_TALL_ONE_PER_CU=0 in the environment: the unmasked kernels two / three per CU)
 find $R -name "*_agent_info.csv" -delete
 grep -v "^$" $R/dense_pmc.md | head -120
