@@ -410,7 +410,7 @@ def fabric_traffic(config, n_gpus):
     return None, None, False
 
 
-def live_fabric_traffic(config, timeout_s=150):
+def live_fabric_traffic(config, timeout_s=90):
     """The counter traffic of THIS library on THIS box, measured inside the run: two short child runs of this very bench
     command (3 steps, no epoch, no CPU legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, only
     --kernel-trace beside them, the program itself after `--`), summarised exactly as profiles/summarize.py summarises the
