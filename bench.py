@@ -916,23 +916,50 @@ def main():
     if parallelism != "single" and not args.no_verify:
         parity = distributed_parity(sg, g, N, F, x, gout, bias, dev, dist)     # collective: every rank takes part
 
+    # The epoch times are SECONDARY measurements: a failure in one of them must not cost the record its headline figure,
+    # which is complete at this point.  An exception is caught and named in `secondary_errors` (a Python-level failure hits
+    # every rank alike -- same code, same shapes -- so the ranks stay in step; a rank that dies alone is what the bounded
+    # collectives and the launcher's fallback are for).
+    secondary_errors = {}
+
+    def secondary(name, fn):
+        import pytextgcn_amd as pkg
+        from pytextgcn_amd import dense as _dense
+        try:
+            return fn()
+        except Exception as e:                       # noqa: BLE001 - reported in the record, the measurement stands
+            secondary_errors[name] = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: {name} failed on rank {rank}: {secondary_errors[name]}", file=sys.stderr, flush=True)
+            return None
+        finally:                                     # whatever happened, the next measurement starts from the defaults
+            pkg.enable_activation_reuse(False)
+            pkg.enable_linear_collapse(False)
+            pkg.enable_fused_dropout(False)
+            _dense.enable_split_gemms(False)
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
-        epoch_ms_fused = sharded_epoch_ms(sg, N, F, C, dev, dist)
-        epoch_ms_reuse = sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True)
-        epoch_ms_w1 = sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True)
-        epoch_ms_w1_reuse = sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True)
+        epoch_ms_fused = secondary("epoch_ms_fused", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist))
+        epoch_ms_reuse = secondary("epoch_ms_fused_with_activation_reuse",
+                                   lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True))
+        epoch_ms_w1 = secondary("epoch_ms_fused_w1_update_in_backward",
+                                lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True))
+        epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
+                                      lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True))
     diagnostics = exchange_diagnostics(sg, F, dev, dist) if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
-        epoch_ms = epoch_time_ms(g, F, C, fused=False)
-        epoch_ms_fused = epoch_time_ms(g, F, C, fused=True)
-        epoch_ms_reuse = epoch_time_ms(g, F, C, fused=True, reuse=True)
-        epoch_ms_collapse = epoch_time_ms(g, F, C, fused=True, collapse=True)
-        epoch_ms_w1 = epoch_time_ms(g, F, C, fused=True, fuse_w1=True)
-        epoch_ms_w1_reuse = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True)    # both switches are bitwise neutral
-        epoch_ms_split = epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True)
+        epoch_ms = secondary("epoch_ms", lambda: epoch_time_ms(g, F, C, fused=False))
+        epoch_ms_fused = secondary("epoch_ms_fused", lambda: epoch_time_ms(g, F, C, fused=True))
+        epoch_ms_reuse = secondary("epoch_ms_fused_with_activation_reuse", lambda: epoch_time_ms(g, F, C, fused=True, reuse=True))
+        epoch_ms_collapse = secondary("epoch_ms_fused_with_collapsed_eval",
+                                      lambda: epoch_time_ms(g, F, C, fused=True, collapse=True))
+        epoch_ms_w1 = secondary("epoch_ms_fused_w1_update_in_backward", lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True))
+        # both switches are bitwise neutral
+        epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
+                                      lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True))
+        epoch_ms_split = secondary("epoch_ms_fused_w1_reuse_split_bf16_gemms",
+                                   lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))
 
     rccl = rccl_info(dist, backend, world, rank, local_rank, dev)        # collective: every rank takes part
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
@@ -1055,6 +1082,7 @@ def main():
             "exchange_diagnostics": diagnostics,
             "exchange_selection": exchange_selection,
             "distributed_parity": parity,
+            "secondary_errors": secondary_errors or None,
             "rccl": rccl,
             "setup_s": setup_s,
         }
