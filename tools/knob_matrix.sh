@@ -16,4 +16,6 @@ run no_hot TGCN_HOT_ROWS=0
 run gemm_split TGCN_GEMM_SPLIT=1
 run big_items TGCN_ITEM_WEIGHT=2048 TGCN_MIN_PIECE=128 TGCN_COL_BLOCK=0
 run small_items TGCN_ITEM_WEIGHT=128 TGCN_MIN_PIECE=8 TGCN_COL_BLOCK=1024
+run many_per_cu TGCN_TALL_ONE_PER_CU=0
+run old_tn TGCN_TN_STAGED_OFF=1
 exit $rc_all
