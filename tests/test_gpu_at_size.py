@@ -209,6 +209,24 @@ def test_config_c4_eight_rank_partition_first_and_last_rank_against_the_oracle(c
     assert sg.symmetric and len(sg.dirs) == 1
     _assert_op_equals(sg.dirs[0].A, _expected_local_csr(sg, ptgt, pcol.long(), pval, "A"))
     _assert_op_equals(sg.dirs[0].B, _expected_local_csr(sg, ptgt, pcol.long(), pval, "B"))
+    # the cut of B_r at local row hp that the fused W1 update uses (ShardedGraph.spmm_adam_w1): the two parts hold B_r's
+    # entries, in B_r's order, and their products are B_r's rows at this size (each part picks its own work partition)
+    d = sg.dirs[0]
+    sg._split_B(d)
+    hp, rp_ = sg.hp, sg.rp
+    brp, bcol, bval = d.B.export_csr()
+    hrp, hcol, hval = d.B_hub.export_csr()
+    rrp, rcol, rval = d.B_reg.export_csr()
+    cut = int(brp[hp].item())
+    assert torch.equal(hrp, brp[:hp + 1]) and torch.equal(rrp, brp[hp:] - cut)
+    assert torch.equal(hcol, bcol[:cut]) and torch.equal(rcol, bcol[cut:])
+    assert torch.equal(hval, bval[:cut]) and torch.equal(rval, bval[cut:])
+    gen = torch.Generator(device=cuda).manual_seed(77)
+    xb = torch.randn(W * hp, 200, device=cuda, generator=gen)
+    xo = torch.randn(rp_, 200, device=cuda, generator=gen)
+    whole = d.B.spmm(xb, None, x2=xo)
+    assert rel_err(d.B_hub.spmm(xb, None, x2=xo), whole[:hp]) < 1e-6
+    assert rel_err(d.B_reg.spmm(xb, None, x2=xo), whole[hp:]) < 1e-6
 
 
 def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5case):
