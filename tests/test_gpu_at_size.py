@@ -227,6 +227,20 @@ def test_config_c4_eight_rank_partition_first_and_last_rank_against_the_oracle(c
     whole = d.B.spmm(xb, None, x2=xo)
     assert rel_err(d.B_hub.spmm(xb, None, x2=xo), whole[:hp]) < 1e-6
     assert rel_err(d.B_reg.spmm(xb, None, x2=xo), whole[hp:]) < 1e-6
+    # ... and tgcn_spmm_adam_split on the regular rows IS tgcn_spmm_split followed by tgcn_adam_step, bit for bit
+    from pytextgcn_amd import _lib
+    from pytextgcn_amd.plan import _stream_ptr
+    lib = _lib.load()
+    p0 = torch.randn(rp_, 200, device=cuda, generator=gen) * 0.01
+    st0 = [torch.rand(rp_, 200, device=cuda, generator=gen) * 1e-3 for _ in range(3)]       # exp_avg, exp_avg_sq, max
+    hyper = (0.05, 0.9, 0.999, 1e-8, 0.0, 3)
+    pf, stf = p0.clone(), [t.clone() for t in st0]
+    d.B_reg.spmm_adam(xb, pf, stf[0], stf[1], stf[2], *hyper, transpose=False, g2=xo)
+    pu, stu = p0.clone(), [t.clone() for t in st0]
+    grad = d.B_reg.spmm(xb, None, x2=xo)
+    _lib.check(lib.tgcn_adam_step(pu.data_ptr(), grad.data_ptr(), stu[0].data_ptr(), stu[1].data_ptr(), stu[2].data_ptr(),
+                                  pu.numel(), *hyper, _stream_ptr(pu.device)))
+    assert torch.equal(pf, pu) and all(torch.equal(a, b) for a, b in zip(stf, stu))
 
 
 def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5case):
