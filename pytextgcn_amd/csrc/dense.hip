@@ -1246,6 +1246,14 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
             return finish();
         }
     }
+    if constexpr (!TRANS_B) {
+        // a column group of a wider layer at the hidden width 200 (DBpedia's 219 classes = 128 + 91 columns): the fully
+        // unrolled k-loop with the counted load ring, as the GCN shape has it (the generic loop leaves 8 MFMAs of cover)
+        if (k == 200 && place.k0 == 0 && !place.accum && (nt == 4 || nt == 3)) {
+            if (nt == 4) TGCN_TALL_K(4, true, 25); else TGCN_TALL_K(3, true, 25);
+            return finish();
+        }
+    }
     if constexpr (TRANS_B) {
     if (whole && k == 64 && nt == 7) {
         if constexpr (DROP) {

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The layer-2 products at config c3's shapes (N = 1 M, hidden 200, 219 classes: column groups / old tn kernel paths)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pytextgcn_amd import dense  # noqa: E402
+
+N, h, C = 1_000_000, 200, 219
+dev = "cuda:0"
+H = torch.randn(N, h, device=dev)
+W = torch.randn(h, C, device=dev)
+G = torch.randn(N, C, device=dev)
+seed = dense.new_seed(dev)
+cases = {"nn": lambda: dense.gemm_nn(H, W), "nn_dropout": lambda: dense.gemm_nn(H, W, 0.5, seed),
+         "nt_colsum": lambda: dense.gemm_nt(G, W, note_colsums=True),
+         "nt_dropout_colsum": lambda: dense.gemm_nt(G, W, 0.5, seed, note_colsums=True),
+         "tn": lambda: dense.gemm_tn(H, G), "tn_dropout": lambda: dense.gemm_tn(H, G, 0.5, seed)}
+ref = {"nn": H.double() @ W.double()}
+print("nn max rel err vs float64:", float((dense.gemm_nn(H, W).double() - ref["nn"]).abs().max() / ref["nn"].abs().max()))
+for name, fn in cases.items():
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(15):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    print(f"  {name:18s} median {ts[len(ts) // 2]:.3f} ms")
