@@ -1482,7 +1482,9 @@ int tgcn_gemm_nt_colsum_mask(const float *A, int64_t lda, const float *B, int64_
 size_t tgcn_gemm_tn_workspace_bytes(int64_t N, int k, int n) {
     if (N < 0 || k <= 0 || n <= 0) return 0;
     // one launch's partial tiles (wider products reuse the region launch after launch)
-    const size_t mpad = 32 * ((std::min(k, tgcn::kGroupK) + 31) / 32), npad = 32 * ((std::min(n, tgcn::kGroupCols) + 31) / 32);
+    size_t nt = (std::min(n, tgcn::kGroupCols) + 31) / 32;
+    if (nt == 3) nt = 4;                                  // three column tiles run as four in the LDS-staged kernel
+    const size_t mpad = 32 * ((std::min(k, tgcn::kGroupK) + 31) / 32), npad = 32 * nt;
     return sizeof(float) * static_cast<size_t>(tgcn::tn_blocks(N)) * mpad * npad;
 }
 
@@ -1534,18 +1536,23 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
             const int ntg = (ng + 31) / 32, mtg = (kg + 31) / 32;
             const float *Ag = A + i0, *Gg = G + j0;
             // 16-byte friendly operands with 1, 2 or 4 column tiles of G: the LDS-staged kernel (rows split over the waves)
-            const bool staged = (ntg == 1 || ntg == 2 || ntg == 4) && kg % 4 == 0 && ng % 4 == 0 && lda % 4 == 0 &&
-                                ldg % 4 == 0 && reinterpret_cast<uintptr_t>(Ag) % 16 == 0 &&
-                                reinterpret_cast<uintptr_t>(Gg) % 16 == 0 && tn_staged_lds_bytes(kg, ng) <= 160 * 1024 &&
+            // A width that is not a multiple of 4 (DBpedia's 219 classes: the second group holds 91 columns) is served when
+            // the row reaches to the next multiple of 4 -- a zero-padded buffer (plan.alloc_padded), or columns of a wider
+            // matrix: what is read there lands in result columns nobody stores.  Three tiles run as four.
+            const int ng4 = (ng + 3) & ~3;
+            const int nts = ntg == 3 ? 4 : ntg;
+            const bool staged = (nts == 1 || nts == 2 || nts == 4) && kg % 4 == 0 && lda % 4 == 0 && ldg % 4 == 0 &&
+                                int64_t(j0) + ng4 <= ldg && reinterpret_cast<uintptr_t>(Ag) % 16 == 0 &&
+                                reinterpret_cast<uintptr_t>(Gg) % 16 == 0 && tn_staged_lds_bytes(kg, ng4) <= 160 * 1024 &&
                                 std::getenv("TGCN_TN_STAGED_OFF") == nullptr;
             if (staged) {
                 const int64_t rpw = ((N + nb - 1) / nb + kTnStageRows - 1) / kTnStageRows * kTnStageRows;
-                const size_t lb = tn_staged_lds_bytes(kg, ng);
+                const size_t lb = tn_staged_lds_bytes(kg, ng4);
 #define TGCN_TNS2(NT, MT_, DR, BI)                                                                                    \
     do {                                                                                                              \
         TGCN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_staged<NT, MT_, DR, BI>),       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb)));       \
-        k_gemm_tn_staged<NT, MT_, DR, BI><<<nb, 256, lb, s>>>(Ag, lda, Gg, ldg, N, kg, ng, rpw, partial,             \
+        k_gemm_tn_staged<NT, MT_, DR, BI><<<nb, 256, lb, s>>>(Ag, lda, Gg, ldg, N, kg, ng4, rpw, partial,            \
                                                               drop ? *drop : Drop{}, i0);                           \
     } while (0)
                 // the recorded mask describes whole rows of A: usable when this launch covers all k columns
@@ -1560,15 +1567,15 @@ static int gemm_tn_impl(const char *fn, const float *A, int64_t lda, const float
         else if (mtg <= 7) TGCN_TNS(NT, 7, DR); else TGCN_TNS(NT, 8, DR);                                           \
     } while (0)
                 if (drop) {
-                    if (ntg == 1) TGCN_TNS_M(1, true); else if (ntg == 2) TGCN_TNS_M(2, true); else TGCN_TNS_M(4, true);
+                    if (nts == 1) TGCN_TNS_M(1, true); else if (nts == 2) TGCN_TNS_M(2, true); else TGCN_TNS_M(4, true);
                 } else {
-                    if (ntg == 1) TGCN_TNS_M(1, false); else if (ntg == 2) TGCN_TNS_M(2, false); else TGCN_TNS_M(4, false);
+                    if (nts == 1) TGCN_TNS_M(1, false); else if (nts == 2) TGCN_TNS_M(2, false); else TGCN_TNS_M(4, false);
                 }
 #undef TGCN_TNS_M
 #undef TGCN_TNS
 #undef TGCN_TNS2
                 TGCN_HIP_CHECK(hipGetLastError());
-                k_gemm_tn_reduce<<<(kg * ng + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mtg, 32 * ntg, kg, ng,
+                k_gemm_tn_reduce<<<(kg * ng + 63) / 64, 256, 0, s>>>(partial, nb, 32 * mtg, 32 * nts, kg, ng,
                                                                      C + int64_t(i0) * ldc + j0, ldc,
                                                                      drop ? drop->scale : 1.0f);
                 TGCN_HIP_CHECK(hipGetLastError());

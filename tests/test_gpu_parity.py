@@ -1258,6 +1258,33 @@ def test_fused_dropout_products_wider_than_one_lds_image(cuda, N, k, n, p):
     assert ((sums.double() - dx.double().sum(0)).abs().max() / dx.double().sum(0).abs().max()).item() < 2e-5
 
 
+@pytest.mark.parametrize("N,h,C", [(50_001, 200, 219), (3000, 200, 91), (777, 64, 7), (4096, 100, 131)])
+def test_weight_gradient_of_a_padded_odd_width(cuda, N, h, C):
+    """dW = x^T @ g for a gradient that arrives as the leading C columns of a zero-padded buffer (plan.alloc_padded: the
+    cross-entropy gradient at DBpedia's 219 classes): the LDS-staged kernel reads the row up to the next multiple of 4
+    and runs three column tiles as four; what it reads in the pad lands in columns nobody stores.  Against float64, and
+    against the same product from a plain contiguous [N, C] gradient (the pre-round-4 kernel's path)."""
+    from pytextgcn_amd import dense
+    from pytextgcn_amd.plan import alloc_padded
+    gen = torch.Generator(device=cuda).manual_seed(N + C)
+    x = torch.randn(N, h, device=cuda, generator=gen)
+    g_plain = torch.randn(N, C, device=cuda, generator=gen)
+    g = alloc_padded(N, C, cuda)
+    g.copy_(g_plain)
+    assert g.stride(0) % 4 == 0 and g.stride(0) >= C
+    ref = x.double().t() @ g_plain.double()
+    got = dense.gemm_tn(x, g)
+    assert tuple(got.shape) == (h, C) and rel_err(got, ref) < TOL
+    assert rel_err(dense.gemm_tn(x, g_plain), ref) < TOL
+    seed = dense.new_seed(cuda)
+    # the same mask either way (another mask would differ in the first digit; the two kernels apply 1 / (1 - p) at different points)
+    assert rel_err(dense.gemm_tn(x, g, 0.4, seed), dense.gemm_tn(x, g_plain, 0.4, seed)) < TOL
+    # garbage behind the columns of a VIEW of a wider matrix does not reach the result
+    wide = torch.full((N, ((C + 3) & ~3) + 4), float("nan"), device=cuda)
+    wide[:, :C] = g_plain
+    assert rel_err(dense.gemm_tn(x, wide[:, :C]), ref) < TOL
+
+
 @pytest.mark.parametrize("C", [219, 7, 64])
 def test_odd_class_width_needs_no_padding_copies_in_the_fused_step(cuda, monkeypatch, C):
     """The float4 SpMM path wants rows of 4 j floats.  For a class count that is no multiple of 4 (DBpedia l3: 219)

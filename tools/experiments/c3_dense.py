@@ -12,13 +12,17 @@ N, h, C = 1_000_000, 200, 219
 dev = "cuda:0"
 H = torch.randn(N, h, device=dev)
 W = torch.randn(h, C, device=dev)
-G = torch.randn(N, C, device=dev)
+from pytextgcn_amd.plan import alloc_padded  # noqa: E402
+G = alloc_padded(N, C, dev)                   # as the cross-entropy gradient arrives: rows of 220 floats, zero pad column
+G.copy_(torch.randn(N, C, device=dev))
 seed = dense.new_seed(dev)
 cases = {"nn": lambda: dense.gemm_nn(H, W), "nn_dropout": lambda: dense.gemm_nn(H, W, 0.5, seed),
          "nt_colsum": lambda: dense.gemm_nt(G, W, note_colsums=True),
          "nt_dropout_colsum": lambda: dense.gemm_nt(G, W, 0.5, seed, note_colsums=True),
          "tn": lambda: dense.gemm_tn(H, G), "tn_dropout": lambda: dense.gemm_tn(H, G, 0.5, seed)}
 ref = {"nn": H.double() @ W.double()}
+print("tn max rel err vs float64:", float((dense.gemm_tn(H, G).double() - H.double().t() @ G.double()).abs().max()
+                                            / (H.double().t() @ G.double()).abs().max()))
 print("nn max rel err vs float64:", float((dense.gemm_nn(H, W).double() - ref["nn"]).abs().max() / ref["nn"].abs().max()))
 for name, fn in cases.items():
     for _ in range(3):
