@@ -124,7 +124,7 @@ __device__ __forceinline__ float drop_elem(float v, uint32_t row_key, uint32_t c
 // BITS (nt with DROP): the mask on the result comes from the record the forward product left (Drop::bits) instead of 16 NT
 // hashes per lane and block -- see the epilogue.
 template <int NT, bool TRANS_B, bool K8, int NQ, bool DROP, bool COLSUM = false, bool BITS = false>
-__global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGCN_TALL_MIN_BLOCKS : 1) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && NQ != 28 && (DROP || COLSUM)) ? TGCN_TALL_MIN_BLOCKS : 1) void k_gemm_tall(const float *__restrict__ A, int64_t lda,
                                                    const float *__restrict__ B, int64_t ldb,
                                                    float *__restrict__ C, int64_t ldc, int64_t N,
                                                    int k, int n, const Drop drop, float *__restrict__ colpart,
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
     extern __shared__ float lds[];  // [kpad][npad] (+ [4][npad] with COLSUM)
     // the fully unrolled kernels (NQ > 0) only ever run whole products: their placement folds to constants, which
     // keeps their register budget where it was (they sit at the limit: an accumulator set + the asm load ring)
-    const int p_col0 = NQ > 0 ? 0 : place.col0, p_k0 = NQ > 0 ? 0 : place.k0;
+    // (the column groups of a wide nt product, NT <= 4, have room for their first column)
+    const int p_col0 = (NQ > 0 && NT > 4) ? 0 : place.col0, p_k0 = NQ > 0 ? 0 : place.k0;
     const bool p_accum = NQ > 0 ? false : place.accum != 0;
     float csum[NT];
 #pragma unroll
@@ -218,8 +219,12 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
             // seven pieces (56 MFMAs) stay in flight.  The wait takes the ring slot as an in/out
             // operand so that no consumer can be scheduled above it.
             f32x4 ring[8];
+            // !K8 (k is not a multiple of 8; the caller guarantees a row stride >= round_up(k, 4)): the LAST piece of a
+            // lane's row may start at or past column k -- it is then loaded from the row's first columns instead (an
+            // address that exists) and zeroed below; a piece that starts before k ends inside the row's stride
+            const float *alast = (K8 || 8 * (NQ - 1) + 4 * half < k) ? arow + 8 * (NQ - 1) : arow;
 #define TGCN_LDA(slot, q) \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[slot]) : "v"(arow + 8 * (q)) : "memory")
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[slot]) : "v"((q) == NQ - 1 ? alast : arow + 8 * (q)) : "memory")
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (j < NQ) TGCN_LDA(j, j);
@@ -243,6 +248,13 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && (DROP || COLSUM)) ? TGC
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[q & 7])::"memory");
                 const f32x4 a = ring[q & 7];
                 float av[4] = {a[0], a[1], a[2], a[3]};
+                if constexpr (!K8) {
+                    if (q == NQ - 1) {                   // columns >= k of the last step: whatever was read there counts as 0
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            if (8 * q + 4 * half + s4 >= k) av[s4] = 0.f;
+                    }
+                }
                 if constexpr (DROP && !TRANS_B) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
@@ -1255,6 +1267,17 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
         }
     }
     if constexpr (TRANS_B) {
+        // a column group of the input-gradient product of a 217 .. 224-class layer (DBpedia l3: 219; hidden 200 = 128 + 72
+        // result columns): 28 unrolled steps with the load ring; needs the operand's rows to reach round_up(k, 4) (the
+        // zero-padded gradient buffer) so that the last piece of a row is read inside it
+        if (k > 216 && k <= 224 && place.k0 == 0 && !place.accum && (nt == 4 || nt == 3) && lda >= ((k + 3) & ~3)) {
+            if (k % 8 == 0) {
+                if (nt == 4) TGCN_TALL_K(4, true, 28); else TGCN_TALL_K(3, true, 28);
+            } else {
+                if (nt == 4) TGCN_TALL_K(4, false, 28); else TGCN_TALL_K(3, false, 28);
+            }
+            return finish();
+        }
     if (whole && k == 64 && nt == 7) {
         if constexpr (DROP) {
             // the mask from the forward product's record: n in (192, 256] has four words per row half (16-byte reads)

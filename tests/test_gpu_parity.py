@@ -1285,6 +1285,40 @@ def test_weight_gradient_of_a_padded_odd_width(cuda, N, h, C):
     assert rel_err(dense.gemm_tn(x, wide[:, :C]), ref) < TOL
 
 
+@pytest.mark.parametrize("N,C", [(50_001, 219), (33, 219), (4096, 224), (1000, 217), (2049, 222)])
+def test_input_gradient_of_a_217_to_224_class_layer_runs_the_unrolled_column_groups(cuda, N, C):
+    """dX = mask * (g @ W^T) at hidden width 200 for DBpedia-sized class counts: two column groups (128 + 72 result
+    columns), each 28 unrolled steps with the load ring; for C % 8 != 0 the last piece of a lane's row is redirected or
+    zeroed -- what lies behind a row (the next row, or NaNs behind the LAST row of the buffer) must not reach the result.
+    Against float64; plain, with column sums, with the mask; and against the generic kernels (unpadded operand)."""
+    from pytextgcn_amd import dense
+    from pytextgcn_amd.plan import alloc_padded, colsum
+    h = 200
+    gen = torch.Generator(device=cuda).manual_seed(N + C)
+    g_plain = torch.randn(N, C, device=cuda, generator=gen)
+    w = torch.randn(h, C, device=cuda, generator=gen)
+    ld = (C + 3) & ~3
+    pool = torch.full((N * ld + 64,), float("nan"), device=cuda)         # NaNs right behind the last row
+    g = pool[:N * ld].view(N, ld)[:, :C]
+    g.copy_(g_plain)
+    if ld > C:
+        pool[:N * ld].view(N, ld)[:, C:] = 0.0                             # the pad columns of an alloc_padded buffer
+    assert g.stride(0) == ld and g.data_ptr() % 16 == 0
+    ref = g_plain.double() @ w.double().t()
+    got = dense.gemm_nt(g, w)
+    assert torch.isfinite(got).all() and rel_err(got, ref) < TOL
+    assert rel_err(dense.gemm_nt(g_plain, w), ref) < TOL                  # the generic kernels (row stride C)
+    got_s = dense.gemm_nt(g, w, note_colsums=True)
+    assert rel_err(got_s, ref) < TOL and rel_err(colsum(got_s), ref.sum(0)) < TOL
+    seed = dense.new_seed(cuda)
+    keep = dense.gemm_nt(torch.ones(N, 8, device=cuda), torch.ones(h, 8, device=cuda), 0.3, seed) != 0
+    got_m = dense.gemm_nt(g, w, 0.3, seed, note_colsums=True)
+    assert rel_err(got_m, ref * keep / 0.7) < TOL and rel_err(colsum(got_m), (ref * keep / 0.7).sum(0)) < TOL
+    pad = alloc_padded(N, C, cuda)
+    pad.copy_(g_plain)
+    assert rel_err(dense.gemm_nt(pad, w), ref) < TOL
+
+
 @pytest.mark.parametrize("C", [219, 7, 64])
 def test_odd_class_width_needs_no_padding_copies_in_the_fused_step(cuda, monkeypatch, C):
     """The float4 SpMM path wants rows of 4 j floats.  For a class count that is no multiple of 4 (DBpedia l3: 219)
