@@ -310,7 +310,7 @@ int tgcn_gemm_tn_dropout(const float *A, int64_t lda, const float *G, int64_t ld
 
 /* The same two products with the keep decisions RECORDED instead of hashed twice: the nn product (forward) writes the mask
  * of its A operand, 4 bits per lane step, `tgcn_dropout_mask_words(k, n)` 32-bit words per row (the caller allocates
- * [N x mask_stride] words; 0 = a product of this shape cannot record it -- chunked reductions, the split-bf16 mode -- use the
+ * [N x mask_stride] words; 0 = a product of this shape cannot record it -- reductions longer than 256, the split-bf16 mode -- use the
  * entry points above); the tn product (weight gradient) reads it back: one load and four bit tests per 16 bytes of A in
  * place of four hashes.  Bit for bit the results of tgcn_gemm_nn_dropout / tgcn_gemm_tn_dropout with the same seed (the
  * tn side falls back on the hash wherever its kernel does not take the record).  Layout: column c of a row is bit 4 ((c / 8) % 8) + (c & 3) of word

@@ -1426,11 +1426,10 @@ int tgcn_gemm_nn_dropout(const float *A, int64_t lda, const float *B, int64_t ld
 }
 
 size_t tgcn_dropout_mask_words(int k, int n) {
-    // recorded by the one-launch fp32 nn product only: the small operand [k x n] must fit the LDS in one piece (the
-    // condition of launch_tall) and the split-bf16 mode must be off (its kernels do not write the record)
-    if (k <= 0 || n <= 0 || tgcn::g_gemm_split.load(std::memory_order_relaxed) != 0) return 0;
-    const size_t kpad = (static_cast<size_t>(k) + 7) & ~size_t(7), npad = 32 * ((static_cast<size_t>(n) + 31) / 32);
-    if (npad > 256 || sizeof(float) * kpad * npad > 160 * 1024) return 0;
+    // recorded by the fp32 nn product whenever its reduction runs in ONE piece (k <= 256: a launch then sees whole rows of
+    // the masked operand; a wide result runs as column groups, each of which writes the same bits) and the split-bf16
+    // mode is off (its kernels do not write the record)
+    if (k <= 0 || n <= 0 || k > tgcn::kGroupK || tgcn::g_gemm_split.load(std::memory_order_relaxed) != 0) return 0;
     return 2 * static_cast<size_t>(tgcn::drop_bits_wph(k));
 }
 

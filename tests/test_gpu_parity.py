@@ -2006,7 +2006,7 @@ def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
 
 
 @pytest.mark.parametrize("N,h,C,p", [(100_003, 200, 64, 0.5), (4097, 100, 20, 0.7), (333, 36, 8, 0.2), (65, 64, 64, 0.5),
-                                     (1, 8, 4, 0.5), (5000, 256, 128, 0.3), (2_000_003, 200, 64, 0.7)])   # the last: c4's rows
+                                     (1, 8, 4, 0.5), (5000, 256, 128, 0.3), (30_001, 200, 219, 0.5), (2_000_003, 200, 64, 0.7)])   # 219: column groups; the last: c4's rows
 def test_recorded_dropout_mask_equals_the_hashed_one(cuda, request, N, h, C, p):
     """tgcn_gemm_nn_dropout_mask leaves its keep decisions as bits (layout documented in include/tgcn.h) and
     tgcn_gemm_tn_dropout_mask reads them back: the record IS the hash's mask (every bit, decoded here), the forward
@@ -2059,6 +2059,7 @@ def test_recorded_dropout_mask_is_refused_where_it_cannot_be_recorded(cuda, requ
     before = dense.enable_split_gemms(False)
     request.addfinalizer(lambda: dense.enable_split_gemms(before))
     assert lib.tgcn_dropout_mask_words(1000, 64) == 0 and lib.tgcn_dropout_mask_words(0, 4) == 0
+    assert lib.tgcn_dropout_mask_words(200, 1000) == 8          # a wide result runs as column groups: still one k piece
     seed = dense.new_seed(cuda)
     x = torch.randn(300, 1000, device=cuda)
     w = torch.randn(1000, 64, device=cuda)

@@ -20,6 +20,10 @@ cases = {"nn": lambda: dense.gemm_nn(H, W), "nn_dropout": lambda: dense.gemm_nn(
          "nt_colsum": lambda: dense.gemm_nt(G, W, note_colsums=True),
          "nt_dropout_colsum": lambda: dense.gemm_nt(G, W, 0.5, seed, note_colsums=True),
          "tn": lambda: dense.gemm_tn(H, G), "tn_dropout": lambda: dense.gemm_tn(H, G, 0.5, seed)}
+_, MASK = dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
+if MASK is not None:
+    cases["nn_dropout_record"] = lambda: dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
+    cases["tn_dropout_from_record"] = lambda: dense.gemm_tn(H, G, 0.5, seed, MASK)
 ref = {"nn": H.double() @ W.double()}
 print("tn max rel err vs float64:", float((dense.gemm_tn(H, G).double() - H.double().t() @ G.double()).abs().max()
                                             / (H.double().t() @ G.double()).abs().max()))
