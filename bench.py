@@ -55,6 +55,10 @@ def parse():
     p.add_argument("--no-hbm-activity", action="store_true", help="skip the live memory-controller measurement")
     p.add_argument("--no-live-traffic", action="store_true",
                    help="N = 1: do not measure the counter traffic in child runs under rocprofv3 (use profiles/traffic.json)")
+    p.add_argument("--mode", choices=["both", "reference", "accurate"], default="both",
+                   help="normalisation mode of the operator (pytextgcn_amd.plan): the headline `value` is ALWAYS the "
+                        "reference-order mode's unless --mode accurate; `both` (default) additionally times the accurate "
+                        "mode in the same run at N = 1 (`value_accurate_mode`)")
     p.add_argument("--launch-check", action="store_true",
                    help="rendezvous only: every rank joins the group, rank 0 prints {launch_check, n_gpus}; no GPU work")
     return p.parse_args()
@@ -124,8 +128,7 @@ def launch_ranks(args) -> int:
         return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                 "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] \
             + sys.argv[1:] + extra
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env = dict(os.environ)          # (HSA_ENABLE_IPC_MODE_LEGACY: decided by every rank itself, sharded.prepare_hsa_env)
     env.setdefault("OMP_NUM_THREADS", "4")
     budget = float(os.environ.get("TGCN_BENCH_BUDGET_S", "420"))
     t0 = time.time()
@@ -208,12 +211,14 @@ def rccl_info(dist, backend, world, rank, local_rank, dev):
             "high_priority_stream": hi, "devices": info}
 
 
-def distributed_parity(sg, g, N, F, x_local, gout_local, bias, dev, dist):
+def distributed_parity(sg, g, N, F, x_local, gout_local, bias, dev, dist, mode):
     """The timed distributed SpMM pair against the SINGLE-DEVICE plan of the same graph, inside the same run: every rank
     builds the whole-graph plan (the graph is on every rank), gathers the operands, and compares ITS rows of `M @ X + b`
     and `M^T @ G` -- so a scaling record carries the evidence that all N ranks computed what one GPU computes (the sums
     associate differently over ranks: max-norm relative error, tolerance 1e-5, not bits).  Collective; never raises: a
-    failure is reported in the record (every rank takes the same branches: decisions are all-reduced)."""
+    failure that hits every rank alike is reported in the record (decisions are all-reduced); a DEVICE error, or a failure
+    on one rank alone (its peers are inside a collective then), is raised to the caller, whose guard (`secondary` in
+    main) ends the run instead of pairing later collectives with the wrong calls."""
     from pytextgcn_amd.plan import GraphPlan
 
     def agree(ok):
@@ -225,27 +230,51 @@ def distributed_parity(sg, g, N, F, x_local, gout_local, bias, dev, dist):
     free = torch.cuda.mem_get_info(dev)[0]
     if not agree(free > 1.5 * need):
         return {"skipped": f"needs about {need / 1e9:.1f} GB free per device"}
-    out = {"tolerance": 1e-5, "against": "single-device GraphPlan of the same edge list, built in this run on every rank"}
+    out = {"tolerance": 1e-5, "normalisation_mode": mode,
+           "against": "single-device GraphPlan of the same edge list and mode, built in this run on every rank"}
+    # the one step that can fail on one rank alone without a collective around it: agree on it before going on
+    plan, err = None, None
     try:
-        errs = []
-        plan = GraphPlan(g.edge_index, g.edge_attr, N)
-        for name, loc, b, tr in (("forward", x_local, bias, False), ("transposed", gout_local, None, True)):
-            full = sg.gather_rows(loc)                                   # collective
-            ref = sg.scatter_rows(plan.spmm(full, b, transpose=tr))
-            mine = sg.spmm(loc, b, transpose=tr)                         # collective
-            scale = float(ref.abs().max().item()) or 1.0
-            e = float((mine[sg.real] - ref[sg.real]).abs().max().item()) / scale if bool(sg.real.any()) else 0.0
-            t = torch.tensor([e], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sg.group)
-            out[f"max_rel_err_{name}"] = t.item()
-            errs.append(t.item())
-            del full, ref, mine
-        out["ok"] = bool(max(errs) < 1e-5)
-        out["rows_checked"] = N
-    except Exception as e:                 # noqa: BLE001 - reported, not raised: the measurement stands
-        out["error"] = f"{type(e).__name__}: {e}"[:300]
+        plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum=mode)
+    except Exception as e:                 # noqa: BLE001 - classified by the caller when it is a device error
+        if is_device_error(e):
+            raise
+        err = f"{type(e).__name__}: {e}"[:300]
+    if not agree(err is None):
+        out["error"] = err or "the single-device plan could not be built on another rank"
+        return out
+    errs = []
+    for name, loc, b, tr in (("forward", x_local, bias, False), ("transposed", gout_local, None, True)):
+        full = sg.gather_rows(loc)                                   # collective
+        ref = sg.scatter_rows(plan.spmm(full, b, transpose=tr))
+        mine = sg.spmm(loc, b, transpose=tr)                         # collective
+        scale = float(ref.abs().max().item()) or 1.0
+        e = float((mine[sg.real] - ref[sg.real]).abs().max().item()) / scale if bool(sg.real.any()) else 0.0
+        t = torch.tensor([e], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sg.group)
+        out[f"max_rel_err_{name}"] = t.item()
+        errs.append(t.item())
+        del full, ref, mine
+    out["ok"] = bool(max(errs) < 1e-5)
+    out["rows_checked"] = N
     out["seconds"] = round(time.perf_counter() - t0, 2)
     return out
+
+
+_DEVICE_ERROR_WORDS = ("hip error", "hiperror", "hsa_status", "hsa error", "memory access fault", "illegal memory access",
+                       "device-side assert", "unspecified launch failure", "hardware exception", "gpu hang")
+
+
+def is_device_error(e) -> bool:
+    """A failure of the device / its runtime (the HIP context may be poisoned), as opposed to a Python-level error:
+    torch's AcceleratorError, or a RuntimeError whose text names HIP / HSA / a fault.  An out-of-memory answer of the
+    allocator is NOT one (the context is intact; torch.OutOfMemoryError)."""
+    if isinstance(e, getattr(torch, "OutOfMemoryError", ())):
+        return False
+    if isinstance(e, getattr(torch, "AcceleratorError", ())):
+        return True
+    text = str(e).lower()
+    return isinstance(e, RuntimeError) and any(w in text for w in _DEVICE_ERROR_WORDS)
 
 
 def cpu_model():
@@ -410,7 +439,7 @@ def fabric_traffic(config, n_gpus):
     return None, None, False
 
 
-def live_fabric_traffic(config, timeout_s=90):
+def live_fabric_traffic(config, mode, timeout_s=90):
     """The counter traffic of THIS library on THIS box, measured inside the run: two short child runs of this very bench
     command (3 steps, no epoch, no CPU legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, only
     --kernel-trace beside them, the program itself after `--`), summarised exactly as profiles/summarize.py summarises the
@@ -432,7 +461,7 @@ def live_fabric_traffic(config, timeout_s=90):
         d = tempfile.mkdtemp(prefix="tgcn_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-               "--no-epoch", "--no-hbm-activity", "--no-live-traffic"]
+               "--no-epoch", "--no-hbm-activity", "--no-live-traffic", "--mode", mode]
         try:
             res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                  timeout=timeout_s)
@@ -665,7 +694,11 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10):
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             return {"max_ms": round(dt.item(), 4), "min_ms": round(lo.item(), 4)}
-        except Exception as e:                       # noqa: BLE001 - diagnostics must never sink the bench line
+        except Exception as e:                       # noqa: BLE001
+            # one rank: a failed phase is a line in the record.  Several ranks: the phase holds collectives, the peers
+            # may be inside one -- the caller's guard (`secondary`) ends the run; a device error is never swallowed
+            if W > 1 or is_device_error(e):
+                raise
             return {"error": f"{type(e).__name__}: {e}"[:200]}
 
     out = {"bytes_each_way_per_collective": int((W - 1) * hp * F * 4)}
@@ -698,6 +731,10 @@ def main():
         sys.exit(launch_ranks(args))
     if args.launch_check:
         sys.exit(launch_check(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))))
+    # both launch paths (a child of launch_ranks, or the driver's own `python -m torch.distributed.run ... bench.py`) come
+    # through here before the first HIP call: ONE place decides the HSA / IPC environment of the rank
+    from pytextgcn_amd.sharded import prepare_hsa_env
+    hsa_env = prepare_hsa_env()
     # stdout carries exactly ONE line (the JSON record): everything else that writes to file descriptor 1
     # -- RCCL prints a version banner there when a communicator is created -- is sent to stderr
     sys.stdout.flush()
@@ -737,6 +774,8 @@ def main():
     from pytextgcn_amd import synth
     from pytextgcn_amd.plan import GraphPlan
 
+    import pytextgcn_amd as _pkg
+    _pkg.set_degree_sum("accurate" if args.mode == "accurate" else "reference")     # what the epoch's GCN / ShardedGCN build
     N, E, F, C = CONFIGS[args.config]
     setup_s = {}                       # wall time of the one-off construction steps (not part of the metric)
     t_setup = time.perf_counter()
@@ -770,22 +809,31 @@ def main():
     bias = torch.randn(F, device=dev, generator=gen)
 
     force_sharded = os.environ.get("TGCN_BENCH_FORCE_SHARDED") == "1"   # rehearse the N>1 path at N=1
+    # The normalisation mode of the operator (pytextgcn_amd/plan.py).  The HEADLINE is the reference-order mode -- the
+    # reference's own arithmetic (PyG-1.6.3 gcn_norm as textgcn/lib/models.py:11-20 runs it: sequential fp32 degree sums,
+    # (dis[src] * w) * dis[dst]), bit for bit the oracle's weights, M^T stored beside M -- because that is the mode whose
+    # results meet BASELINE.json's 1e-5 against the reference formulation on this very graph.  The accurate mode (float64
+    # degree sums, bitwise symmetric operator, no stored M^T) is timed beside it at N = 1.
+    headline_mode = "accurate" if args.mode == "accurate" else "reference"
     if world == 1 and not force_sharded:
-        plan = GraphPlan(g.edge_index, g.edge_attr, N)
+        plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum=headline_mode)
         x = torch.randn(N, F, device=dev, generator=gen)
         gout = torch.randn(N, F, device=dev, generator=gen)
         y = torch.empty(N, F, device=dev)
         dxw = torch.empty(N, F, device=dev)
 
-        def step(ev=None):
-            if ev is not None:
-                ev[0].record()
-            plan.spmm(x, bias, out=y)
-            if ev is not None:
-                ev[1].record()
-            plan.spmm(gout, None, transpose=True, out=dxw)
-            if ev is not None:
-                ev[2].record()
+        def make_step(pl):
+            def step(ev=None):
+                if ev is not None:
+                    ev[0].record()
+                pl.spmm(x, bias, out=y)
+                if ev is not None:
+                    ev[1].record()
+                pl.spmm(gout, None, transpose=True, out=dxw)
+                if ev is not None:
+                    ev[2].record()
+            return step
+        step = make_step(plan)
         bytes_fwd = plan.algorithmic_bytes(F, bias=True)
         bytes_bwd = plan.algorithmic_bytes(F, bias=False, transpose=True)
         parallelism = "single"
@@ -799,7 +847,7 @@ def main():
         # word nodes: replicated operand block; a graph without them (c5) has no hub structure -> every node's
         # rows may be needed anywhere: the halo exchange sends the referenced ones
         hubs = torch.arange(N, device=dev) < g.n_vocab if g.n_vocab > 0 else None
-        sg = ShardedGraph(g.edge_index, g.edge_attr, N, group=dist.group.WORLD, hubs=hubs)
+        sg = ShardedGraph(g.edge_index, g.edge_attr, N, group=dist.group.WORLD, hubs=hubs, degree_sum=headline_mode)
         x = torch.randn(sg.n_local, F, device=dev, generator=gen)
         gout = torch.randn(sg.n_local, F, device=dev, generator=gen)
 
@@ -886,56 +934,115 @@ def main():
     if exchange_selection is not None:
         torch.cuda.synchronize()
         setup_s["exchange_trial_steps"] = round(time.perf_counter() - t_setup, 3)
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    # per-launch kernel time of the SpMM op (k_spmm_gather + k_spmm_fix) from HIP events recorded
-    # on the launch stream inside the timed region
-    ms_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    ms_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    def timed(step_fn):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides (max over ranks);
+        per-launch kernel time of the SpMM op from HIP events recorded on the launch stream inside the timed region."""
+        for _ in range(args.warmup):
+            step_fn()
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step_fn(events[k])
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return (dt, sum(e[0].elapsed_time(e[1]) for e in events) / args.steps,
+                sum(e[1].elapsed_time(e[2]) for e in events) / args.steps)
+    elapsed, ms_fwd, ms_bwd = timed(step)
     launch_ms = 0.5 * (ms_fwd + ms_bwd)
+    # the accurate mode beside it: same graph, same operands, same K / W, same bracket (N = 1)
+    other_mode = None
+    if parallelism == "single" and args.mode == "both":
+        plan_acc = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")
+        el2, f2, b2 = timed(make_step(plan_acc))
+        other_mode = {"mode": "accurate", "value": 2.0 * E / (el2 / args.steps), "ms_per_step": el2 / args.steps * 1e3,
+                      "launch_ms_fwd": f2, "launch_ms_bwd": b2, "stores_transpose": not plan_acc.symmetric,
+                      "plan_device_bytes": plan_acc.stats()["device_bytes"]}
+        plan_acc.close()
+        del plan_acc
     launch_bytes = 0.5 * (bytes_fwd + bytes_bwd)
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
+
+    # ---- the headline, complete at this point; everything below is secondary ------------------------------------------
+    secondary_errors = {}
+    workload = (f"{args.config}: synthetic {'power-law graph' if args.config == 'c5' else 'PMI/TF-IDF word-doc graph'}, N={N}, "
+                f"E={E}, nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G; "
+                + ("normalisation mode 'reference' (PyG-1.6.3 gcn_norm's own fp32 arithmetic, weights bit for bit the "
+                   "oracle's; M^T stored beside M)" if headline_mode == "reference" else
+                   "normalisation mode 'accurate' (float64 degree sums, bitwise symmetric operator)"))
+    headline = {
+        "metric": "edges/sec (fwd+bwd SpMM), 2M-node/50M-edge graph h=200"
+                  if args.config == "c4" else f"edges/sec (fwd+bwd SpMM), {args.config}",
+        "value": 2.0 * E / (elapsed / args.steps), "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "normalisation_mode": headline_mode, "parallelism": parallelism}}
+    state = {"written": False}
+
+    def write_record(rec):
+        if rank == 0 and not state["written"]:
+            state["written"] = True
+            os.write(json_fd, (json.dumps(rec) + "\n").encode())
+
+    def abort(where, err):
+        """A failure that must not be swallowed (see `secondary`): rank 0 writes the headline it holds, marked as an aborted
+        run, and every rank that gets here exits non-zero WITHOUT tearing the group down (its peers may sit in a collective;
+        torch.distributed.run ends them when this rank is gone)."""
+        print(f"bench.py: rank {rank} aborts in {where}: {err}", file=sys.stderr, flush=True)
+        write_record(dict(headline, aborted={"in": where, "error": err, "rank": rank},
+                          secondary_errors=dict(secondary_errors, **{where: err})))
+        sys.stderr.flush()
+        os._exit(1)
+    if rank == 0 and world > 1:
+        # a peer that aborts makes torch.distributed.run send SIGTERM to the rest: rank 0 still hands the headline over
+        import signal
+
+        def on_term(signum, frame):
+            write_record(dict(headline, aborted={"in": "SIGTERM (a peer rank ended)", "rank": 0},
+                              secondary_errors=secondary_errors or None))
+            os._exit(1)
+        signal.signal(signal.SIGTERM, on_term)
 
     # what the SpMM pulls from HBM, measured live on this box (outside the timed region; N = 1 only: at N > 1
     # the step contains collectives every rank must enter)
     hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
 
-    parity = None
-    if parallelism != "single" and not args.no_verify:
-        parity = distributed_parity(sg, g, N, F, x, gout, bias, dev, dist)     # collective: every rank takes part
-
-    # The epoch times are SECONDARY measurements: a failure in one of them must not cost the record its headline figure,
-    # which is complete at this point.  An exception is caught and named in `secondary_errors` (a Python-level failure hits
-    # every rank alike -- same code, same shapes -- so the ranks stay in step; a rank that dies alone is what the bounded
-    # collectives and the launcher's fallback are for).
-    secondary_errors = {}
-
     def secondary(name, fn):
+        """One guarded secondary measurement; the headline is complete before the first of them.
+          * N = 1: a Python-level failure is named in `secondary_errors` and the run goes on.  A DEVICE error (the message
+            names HIP / HSA / a memory fault) poisons the context and is never swallowed: `abort()` writes the headline,
+            marked aborted, and the process exits non-zero.
+          * N > 1: the guarded code contains collectives, so a rank that raises may have left its peers inside one, and any
+            collective it enters next (were it only to agree on the outcome) could pair with a different call of theirs.
+            Every failure therefore ends the run the same way: `abort()` -- rank 0 still hands over the headline (itself,
+            or from its SIGTERM handler when a peer went first), torch.distributed.run ends the other ranks, and the
+            launcher (launch_ranks) runs the plain configuration in a fresh child."""
         import pytextgcn_amd as pkg
         from pytextgcn_amd import dense as _dense
         try:
             return fn()
-        except Exception as e:                       # noqa: BLE001 - reported in the record, the measurement stands
-            secondary_errors[name] = f"{type(e).__name__}: {e}"[:300]
-            print(f"bench.py: {name} failed on rank {rank}: {secondary_errors[name]}", file=sys.stderr, flush=True)
+        except Exception as e:                       # noqa: BLE001 - classified here
+            err = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: {name} failed on rank {rank}: {err}", file=sys.stderr, flush=True)
+            if world > 1 or is_device_error(e):
+                abort(name, err)
+            secondary_errors[name] = err
             return None
         finally:                                     # whatever happened, the next measurement starts from the defaults
             pkg.enable_activation_reuse(False)
             pkg.enable_linear_collapse(False)
             pkg.enable_fused_dropout(False)
             _dense.enable_split_gemms(False)
+
+    parity = None
+    if parallelism != "single" and not args.no_verify:
+        parity = secondary("distributed_parity",                              # collective: every rank takes part
+                           lambda: distributed_parity(sg, g, N, F, x, gout, bias, dev, dist, headline_mode))
+
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
@@ -946,7 +1053,8 @@ def main():
                                 lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True))
         epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
                                       lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True))
-    diagnostics = exchange_diagnostics(sg, F, dev, dist) if (world > 1 or force_sharded) else None
+    diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
+        if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = secondary("epoch_ms", lambda: epoch_time_ms(g, F, C, fused=False))
@@ -962,6 +1070,7 @@ def main():
                                    lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))
 
     rccl = rccl_info(dist, backend, world, rank, local_rank, dev)        # collective: every rank takes part
+    rccl["hsa_env"] = hsa_env
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -982,7 +1091,7 @@ def main():
         if parallelism == "single" and not args.no_live_traffic and not args.no_hbm_activity:
             # the counters of THIS run's library on THIS box (two short child runs under rocprofv3), so that `traffic` is
             # not a constant the builder committed; the committed figure stays in the record beside it
-            live, live_note = live_fabric_traffic(args.config)
+            live, live_note = live_fabric_traffic(args.config, headline_mode)
             if live is not None:
                 fabric, fabric_src, fabric_fresh = live, live_note, True
         hbm_bytes = None
@@ -1046,22 +1155,14 @@ def main():
             "frac_hbm_of_device_copy": None if hbm_bytes is None else hbm_bytes * per_s / copy_gbps,
             "launch_ms": launch_ms, "launch_ms_fwd": ms_fwd, "launch_ms_bwd": ms_bwd,
             "algorithmic_bytes_per_launch": launch_bytes}
-        out = {
-            "metric": "edges/sec (fwd+bwd SpMM), 2M-node/50M-edge graph h=200"
-                      if args.config == "c4" else f"edges/sec (fwd+bwd SpMM), {args.config}",
-            "value": 2.0 * E / (elapsed / args.steps),
-            "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: synthetic "
-                                   f"{'power-law graph' if args.config == 'c5' else 'PMI/TF-IDF word-doc graph'}, N={N}, E={E}, "
-                                   f"nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G",
-                       "parallelism": parallelism},
+        out = dict(headline)
+        out.update({
+            # the same step with the operator normalised in the accurate mode (opt-in: float64 degree sums, one stored
+            # block), timed in this run with the same K / W; NOT the headline
+            "value_accurate_mode": other_mode["value"] if other_mode else None,
+            "accurate_mode": other_mode,
+            "plan": {"mode": headline_mode, "stores_transpose": not getattr(plan, "symmetric", False),
+                     "device_bytes": plan.stats().get("device_bytes") if hasattr(plan, "stats") else None},
             "roofline": roofline,
             "epoch_ms": epoch_ms,
             "epoch_ms_fused": epoch_ms_fused,
@@ -1085,11 +1186,11 @@ def main():
             "secondary_errors": secondary_errors or None,
             "rccl": rccl,
             "setup_s": setup_s,
-        }
+        })
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E,
                                                full={"auto": "auto", "full": True, "sample": False}[args.cpu_ref])
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        write_record(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,7 +19,10 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytextgcn_amd import Text2GraphTransformer, optim, synth  # noqa: E402
-from pytextgcn_amd.sharded import ShardedGCN, ShardedGraph, init_process_group, sharded_cross_entropy  # noqa: E402
+from pytextgcn_amd.sharded import (ShardedGCN, ShardedGraph, init_process_group, prepare_hsa_env,  # noqa: E402
+                                   sharded_cross_entropy)
+
+prepare_hsa_env()                                  # before the first HIP call of this rank (dmabuf IPC for RCCL)
 
 p = argparse.ArgumentParser()
 p.add_argument("--docs", type=int, default=20000)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 4
+#define TGCN_ABI_VERSION 5
 
 enum {
     TGCN_OK = 0,
@@ -329,6 +329,17 @@ int tgcn_gemm_nt_colsum_mask(const float *A, int64_t lda, const float *B, int64_
                              int64_t N, int k, int n, double p, const uint64_t *seed, const uint32_t *mask,
                              int64_t mask_stride, float *colsum, void *workspace, size_t workspace_bytes,
                              tgcn_stream stream);
+/* tgcn_set_dropout_row_keys -- which ROW of the dropout mask a row of the masked matrix is, for every tgcn_gemm_*_dropout*
+ * / tgcn_gemm_nt_colsum* call this THREAD makes from now on: row i of the call's [N x ld] matrix takes the keep decisions
+ * of mask row i + key0 when i < split, of mask row i + key1 otherwise (the mask is a stateless hash of (seed, mask row,
+ * column)).  (0, 0, 0) -- the state of a new thread -- is the row index itself.  No reference counterpart (F.dropout at
+ * textgcn/lib/models.py:23 draws an unkeyed mask over the whole activation); it exists for the 1-D partition: a hub
+ * (word) row's mask must be the same function of its position in the gathered hub block on the rank that owns the row
+ * (its local rows [0, hp) are mask rows rank * hp + i) and on every rank that holds a partial sum of it, so that
+ * dropout(sum_q P_q) @ W2 = sum_q dropout(P_q) @ W2 can be exchanged at the class width (pytextgcn_amd/sharded.py,
+ * `narrow_exchange`).  The recorded-mask entry points record / read decisions per matrix row, whatever the keys. */
+int tgcn_set_dropout_row_keys(int64_t split, int64_t key0, int64_t key1);
+
 /* tgcn_set_gemm_split -- library-wide numerical mode of tgcn_gemm_nn / _nt / _tn for the
  * shapes of the GCN layers (nn: k = 200, 33 <= n <= 64; nt: k = 64, 193 <= n <= 224; tn: k = 200, 33 <= n <= 64,
  * contiguous operands; + the _dropout forms and, for nt, the _colsum form).  Every other shape keeps the fp32 kernels.  on != 0: every fp32 product is

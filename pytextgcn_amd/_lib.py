@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .build import LIB_PATH
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
 NORM_OFF, NORM_ACCURATE, NORM_REFERENCE = 0, 1, 2          # `normalize` of tgcn_plan_create
@@ -85,6 +85,7 @@ SIGNATURES = {
     "tgcn_gemm_nt_colsum_mask": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                          c_double, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tgcn_set_gemm_split": (c_int, [c_int]),
+    "tgcn_set_dropout_row_keys": (c_int, [c_int64, c_int64, c_int64]),
     "tgcn_gemm_nt_colsum_workspace_bytes": (c_size_t, [c_int]),
     "tgcn_gemm_nt_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                     c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -63,7 +63,16 @@ struct Drop {
     int ld;                // logical width of the masked matrix
     uint32_t *bits;        // optional record of the keep decisions (layout: drop_bits_word / _shift below); the nn
     int64_t bits_stride;   // product writes it, the tn product reads it instead of hashing every element again
+    // Which ROW of the mask a row of this call's matrix is (tgcn_set_dropout_row_keys): row i hashes as i + key0 when
+    // i < key_split, else as i + key1.  All zero: the row index itself.  The 1-D partition uses it so that a hub row's
+    // mask is a function of its position in the GATHERED hub block -- the same on the rank that owns the row (its rows
+    // [0, hp) hash as rank * hp + i) and on every rank that holds a partial sum of it (pytextgcn_amd/sharded.py).
+    int64_t key_split, key0, key1;
 };
+
+__device__ __forceinline__ int64_t drop_row_of(const Drop &d, int64_t row) {
+    return row + (row < d.key_split ? d.key0 : d.key1);
+}
 
 // The recorded keep mask of a [N x k] operand: 4 bits per (row, 8-column step q, lane half h) -- the 4 consecutive
 // columns 8 q + 4 h .. + 3 a lane of the nn kernel multiplies in step q -- packed 8 steps to a word; a row holds the
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && NQ != 28 && (DROP || CO
         uint32_t mword = 0;                    // the keep decisions of up to 8 steps, on their way to drop.bits
         uint32_t *mrow = nullptr;
         if constexpr (DROP && !TRANS_B) {
-            a_key = drop_row_key(s_lo, s_hi, row);
+            a_key = drop_row_key(s_lo, s_hi, drop_row_of(drop, row));
             if (drop.bits) mrow = drop.bits + row * drop.bits_stride + half * drop_bits_wph(k);
         }
         // BITS: this block's slice of the recorded mask, 32 rows x 8 words = 1 KB: lane l fetches the 4 words of half l & 1
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && NQ != 28 && (DROP || CO
         if constexpr (DROP && TRANS_B) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
+                c_key[i] = drop_row_key(s_lo, s_hi, drop_row_of(drop, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half));
         }
         // The lane's first row and its address are formed ONCE per block; element (i, t) then sits at the wave-uniform
         // offset ((i&3) + 8*(i>>2)) * ldc + 32 t from it (scalar arithmetic, one 64-bit add per store).  Round 4: written
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const floa
     for (int64_t blk = int64_t(blockIdx.x) * kSplitWaves + wave; blk < n_blocks; blk += int64_t(gridDim.x) * kSplitWaves) {
         const int64_t row = blk * 32 + r;
         uint32_t a_key = 0;
-        if constexpr (DROP && !TRANS_B) a_key = drop_row_key(s_lo, s_hi, row);
+        if constexpr (DROP && !TRANS_B) a_key = drop_row_key(s_lo, s_hi, drop_row_of(drop, row));
         const float *arow = A + std::min(row, N - 1) * lda;
         f32x16 acc[NT];
 #pragma unroll
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void k_gemm_tall_split(const floa
         if constexpr (DROP && TRANS_B) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                c_key[i] = drop_row_key(s_lo, s_hi, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half);
+                c_key[i] = drop_row_key(s_lo, s_hi, drop_row_of(drop, blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * half));
         }
         if (row_stores) {
             const int64_t rows_here = std::min<int64_t>(32, N - blk * 32);
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         for (int u = 0; u < UR; ++u) {
             float x0 = a0[buf][u], x1 = a1[buf][u];
             if constexpr (DROP) {
-                const uint32_t key = drop_row_key(s_lo, s_hi, stage_row[buf] + 2 * u);
+                const uint32_t key = drop_row_key(s_lo, s_hi, drop_row_of(drop, stage_row[buf] + 2 * u));
                 x0 = drop_elem(x0, key, drop_col_term(k0 + ca0), drop);
                 x1 = drop_elem(x1, key, drop_col_term(k0 + ca1), drop);
             }
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float *__restr
         const float s = ok ? 1.f : 0.f;
         float x0 = pa0[-back * lda] * s, x1 = pa1[-back * lda] * s;
         if constexpr (DROP) {
-            const uint32_t key = drop_row_key(s_lo, s_hi, r_begin + r + half - back);
+            const uint32_t key = drop_row_key(s_lo, s_hi, drop_row_of(drop, r_begin + r + half - back));
             x0 = drop_elem(x0, key, drop_col_term(k0 + ca0), drop);
             x1 = drop_elem(x1, key, drop_col_term(k0 + ca1), drop);
         }
@@ -888,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restri
                     v.z = __uint_as_float(__float_as_uint(v.z) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift + 2, 1)));
                     v.w = __uint_as_float(__float_as_uint(v.w) & uint32_t(__builtin_amdgcn_sbfe(w, b_shift + 3, 1)));
                 } else if constexpr (DROP) {
-                    const uint32_t key = drop_row_key_uniform(s_lo, s_hi, row0 + wave + 4 * u);
+                    const uint32_t key = drop_row_key_uniform(s_lo, s_hi, drop_row_of(drop, row0 + wave + 4 * u));
                     v.x = drop_keep(key, drop_col_term(k0 + 4 * lane), drop) ? v.x : 0.f;
                     v.y = drop_keep(key, drop_col_term(k0 + 4 * lane + 1), drop) ? v.y : 0.f;
                     v.z = drop_keep(key, drop_col_term(k0 + 4 * lane + 2), drop) ? v.z : 0.f;
@@ -1059,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_split(const float *__restric
         for (int j = 0; j < 8; ++j) {
             float v0 = la[j * kp + ca0], v1 = la[j * kp + ca1];
             if constexpr (DROP) {
-                const uint32_t key = drop_row_key(s_lo, s_hi, row0 + 8 * half + j);
+                const uint32_t key = drop_row_key(s_lo, s_hi, drop_row_of(drop, row0 + 8 * half + j));
                 v0 = drop_elem(v0, key, drop_col_term(ca0), drop);
                 v1 = drop_elem(v1, key, drop_col_term(ca1), drop);
             }
@@ -1390,6 +1399,21 @@ static int gemm_nt_impl(const char *fn, const float *A, int64_t lda, const float
                 : launch_tall<true, false>(A, lda, B, ldb, C, ldc, N, k, n, Drop{}, s);
 }
 
+// tgcn_set_dropout_row_keys: which mask row a matrix row is, for the dropout products this THREAD launches next
+static thread_local int64_t t_key_split = 0, t_key0 = 0, t_key1 = 0;
+
+int tgcn_set_dropout_row_keys(int64_t split, int64_t key0, int64_t key1) {
+    if (split < 0 || key0 < 0 || key1 < 0) {
+        tgcn::set_error("tgcn_set_dropout_row_keys: split, key0 and key1 must be >= 0 (%lld, %lld, %lld)", (long long)split,
+                        (long long)key0, (long long)key1);
+        return TGCN_E_INVALID;
+    }
+    t_key_split = split;
+    t_key0 = key0;
+    t_key1 = key1;
+    return TGCN_OK;
+}
+
 // p in [0, 1]; p = 1 drops everything (scale 0, as torch does)
 static int make_drop(const char *fn, double p, const uint64_t *seed, int ld, tgcn::Drop &d) {
     if (!(p >= 0.0 && p <= 1.0) || !seed) {
@@ -1398,6 +1422,9 @@ static int make_drop(const char *fn, double p, const uint64_t *seed, int ld, tgc
     }
     d.seed = seed;
     d.ld = ld;
+    d.key_split = t_key_split;
+    d.key0 = t_key0;
+    d.key1 = t_key1;
     if (p >= 1.0) {
         d.thresh = 0xffffffffu;
         d.scale = 0.f;

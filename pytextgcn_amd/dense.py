@@ -46,11 +46,29 @@ def _check_seed(seed: Tensor, dev) -> None:
         raise TypeError("dropout seed must be a one-element int64 tensor on the operand's device")
 
 
-def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_mask: bool = False):
+class _row_keys:
+    """`with _row_keys(lib, keys):` -- the dropout products launched inside take mask row i + key0 for row i < split and
+    i + key1 otherwise (`tgcn_set_dropout_row_keys`, keys = (split, key0, key1)); the thread's state is put back to the
+    identity on the way out, so no call outside this module ever sees keys it did not ask for."""
+
+    def __init__(self, lib, keys):
+        self.lib, self.keys = lib, keys
+
+    def __enter__(self):
+        if self.keys is not None:
+            _lib.check(self.lib.tgcn_set_dropout_row_keys(*(int(v) for v in self.keys)))
+
+    def __exit__(self, *exc):
+        if self.keys is not None:
+            self.lib.tgcn_set_dropout_row_keys(0, 0, 0)
+        return False
+
+
+def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_mask: bool = False, keys=None):
     """a [N, k] @ b [k, n]; with `seed`: dropout(a, p) @ b, the mask regenerated from the seed.
     `record_mask` (with `seed`): returns (product, mask) where `mask` is the kernel's record of its keep decisions
     ([N, words] int32, `tgcn_gemm_nn_dropout_mask`) for `gemm_tn(..., mask=...)`, or None when a product of this shape
-    cannot record it."""
+    cannot record it.  `keys` = (split, key0, key1): which mask row a row of `a` is (see `_row_keys`)."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
@@ -63,17 +81,18 @@ def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_ma
     else:
         _check_seed(seed, a.device)
         words = int(lib.tgcn_dropout_mask_words(k, n)) if record_mask else 0
-        if words:
-            mask = torch.empty(N, words, dtype=torch.int32, device=a.device)
-            _lib.check(lib.tgcn_gemm_nn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
-                                                     _stream_ptr(a.device)))
-        else:
-            _lib.check(lib.tgcn_gemm_nn_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
+        with _row_keys(lib, keys):
+            if words:
+                mask = torch.empty(N, words, dtype=torch.int32, device=a.device)
+                _lib.check(lib.tgcn_gemm_nn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                         _stream_ptr(a.device)))
+            else:
+                _lib.check(lib.tgcn_gemm_nn_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
     return (c, mask) if record_mask else c
 
 
 def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_colsums: bool = False,
-            mask: Tensor = None) -> Tensor:
+            mask: Tensor = None, keys=None) -> Tensor:
     """a [N, k] @ b[n, k]^T; with `seed` the [N, n] result is masked and scaled (dropout backward).
     `note_colsums`: the kernel also sums the columns of the result it stores and the sums are recorded for
     `plan.colsum` (the result is a gradient on its way to a layer with a bias).  `mask` (with `seed` and `note_colsums`):
@@ -91,26 +110,28 @@ def gemm_nt(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, note_cols
         sums = torch.empty(n, dtype=torch.float32, device=a.device)
         ws_bytes = lib.tgcn_gemm_nt_colsum_workspace_bytes(n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-        if mask is not None and seed is not None:
-            if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
-                    mask.stride(1) != 1:
-                raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
-            _lib.check(lib.tgcn_gemm_nt_colsum_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
-                                                    sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
-        else:
-            _lib.check(lib.tgcn_gemm_nt_colsum(*args, float(p), seed.data_ptr() if seed is not None else None,
-                                               sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
+        with _row_keys(lib, keys if seed is not None else None):
+            if mask is not None and seed is not None:
+                if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
+                        mask.stride(1) != 1:
+                    raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
+                _lib.check(lib.tgcn_gemm_nt_colsum_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                        sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
+            else:
+                _lib.check(lib.tgcn_gemm_nt_colsum(*args, float(p), seed.data_ptr() if seed is not None else None,
+                                                   sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(a.device)))
         note_colsum(c, sums)
         return c
     if seed is None:
         _lib.check(lib.tgcn_gemm_nt(*args, _stream_ptr(a.device)))
     else:
         _check_seed(seed, a.device)
-        _lib.check(lib.tgcn_gemm_nt_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
+        with _row_keys(lib, keys):
+            _lib.check(lib.tgcn_gemm_nt_dropout(*args, float(p), seed.data_ptr(), _stream_ptr(a.device)))
     return c
 
 
-def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None, mask: Tensor = None) -> Tensor:
+def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None, mask: Tensor = None, keys=None) -> Tensor:
     """a[N, k]^T @ g[N, n]; with `seed`: dropout(a, p)^T @ g; `mask`: the record `gemm_nn(..., record_mask=True)` left
     of the same dropout (same bits as hashing from the seed, without the hashing)."""
     lib = _lib.load()
@@ -128,15 +149,16 @@ def gemm_tn(a: Tensor, g: Tensor, p: float = 0.0, seed: Tensor = None, mask: Ten
         _lib.check(lib.tgcn_gemm_tn(*args, ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
     else:
         _check_seed(seed, a.device)
-        if mask is not None:
-            if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
-                    mask.stride(1) != 1:
-                raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
-            _lib.check(lib.tgcn_gemm_tn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
-                                                     ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
-        else:
-            _lib.check(lib.tgcn_gemm_tn_dropout(*args, float(p), seed.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                _stream_ptr(a.device)))
+        with _row_keys(lib, keys):
+            if mask is not None:
+                if mask.dtype != torch.int32 or mask.device != a.device or mask.dim() != 2 or mask.size(0) != N or \
+                        mask.stride(1) != 1:
+                    raise TypeError("mask must be the [N, words] int32 record of gemm_nn(..., record_mask=True)")
+                _lib.check(lib.tgcn_gemm_tn_dropout_mask(*args, float(p), seed.data_ptr(), mask.data_ptr(), mask.stride(0),
+                                                         ws.data_ptr(), ws.numel(), _stream_ptr(a.device)))
+            else:
+                _lib.check(lib.tgcn_gemm_tn_dropout(*args, float(p), seed.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    _stream_ptr(a.device)))
     return c
 
 

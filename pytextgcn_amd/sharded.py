@@ -37,6 +37,29 @@ from torch import Tensor, nn
 from .conv import glorot_
 
 
+def prepare_hsa_env() -> dict:
+    """The ONE place that decides the process environment of a multi-process GPU run; every rank passes it before its
+    first HIP call (bench.py main(), `init_process_group`, the examples, the test workers).
+
+    HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool supports only dmabuf IPC; with the legacy mode RCCL's
+    P2P / shared-memory transports (and any device-tensor sharing between processes) fail with `hipIpcGetMemHandle:
+    invalid argument`.  The image exports it already; a launcher that builds its own environment may have dropped it, so
+    it is set here when absent -- which only helps while the HSA runtime has not been initialised yet in this process
+    (it reads the variable once).  Returns what a bench record reports under `rccl`."""
+    import os
+    import warnings
+    name = "HSA_ENABLE_IPC_MODE_LEGACY"
+    before = os.environ.get(name)
+    late = False
+    if before is None:
+        late = torch.cuda.is_initialized()
+        os.environ[name] = "0"
+        if late:
+            warnings.warn(f"pytextgcn_amd.sharded: {name} was unset and the GPU runtime is already initialised in this "
+                          "process; set it to 0 in the launching environment (RCCL between processes needs dmabuf IPC here)")
+    return {name: os.environ[name], "was_set_by_the_launcher": before is not None, "set_after_hip_init": late}
+
+
 def init_process_group(backend: str = "nccl", device: Optional[torch.device] = None, timeout_s: Optional[float] = None,
                        **kw) -> None:
     """torch.distributed.init_process_group for the 1-D partition.  With RCCL (backend "nccl") the communicator's
@@ -45,6 +68,8 @@ def init_process_group(backend: str = "nccl", device: Optional[torch.device] = N
     `ShardedGraph.spmm` is built around would run one phase after the other.  `timeout_s` bounds every collective (a
     dead peer then ends the process instead of hanging it)."""
     import datetime
+    import warnings
+    prepare_hsa_env()
     if timeout_s is not None:
         kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
     if backend != "nccl":
@@ -57,10 +82,26 @@ def init_process_group(backend: str = "nccl", device: Optional[torch.device] = N
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
     except (AttributeError, TypeError):
         pass
-    try:
-        dist.init_process_group("nccl", pg_options=opts, **kw)
-    except TypeError:                      # a torch that spells the argument differently: default options
-        dist.init_process_group("nccl", **kw)
+    # a torch that spells an argument differently: drop what it refuses, one argument at a time, and SAY what was lost
+    # (without the high-priority stream the exchange queues behind the SpMM grids instead of overlapping them)
+    attempts = [dict(kw, pg_options=opts)] if opts is not None else []
+    attempts.append(dict(kw))
+    if "device_id" in kw:
+        attempts.append({k: v for k, v in kw.items() if k != "device_id"})
+    last = None
+    for i, args in enumerate(attempts):
+        try:
+            dist.init_process_group("nccl", **args)
+        except TypeError as e:
+            last = e
+            continue
+        if opts is None or "pg_options" not in args:
+            warnings.warn("pytextgcn_amd.sharded: this torch did not take the high-priority-stream option of the RCCL "
+                          "group; the collectives of ShardedGraph.spmm will not overlap the local SpMMs")
+        if "device_id" in kw and "device_id" not in args:
+            warnings.warn("pytextgcn_amd.sharded: this torch did not take `device_id`; the communicator binds lazily")
+        return
+    raise last
 
 
 def let_rccl_ranks_share_a_device(rank: int) -> None:
@@ -83,7 +124,7 @@ def let_rccl_ranks_share_a_device(rank: int) -> None:
 # --------------------------------------------------------------------------------------------------
 class HipEngine:
     def gcn_norm(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                 add_self_loops: int, degree_sum: str = "accurate") -> Tuple[Tensor, Tensor]:
+                 add_self_loops: int, degree_sum: str = "reference") -> Tuple[Tensor, Tensor]:
         """(dis, loop_w): deg^-1/2 per node (in-degree at the target incl. the self loop, inf -> 0) and the
         weight of every node's self loop, from the WHOLE edge list -- libtgcn.so `tgcn_gcn_norm`, which walks
         the edges in bounded chunks: no whole-graph plan, no nnz-sized temporaries.  It is the routine
@@ -322,9 +363,10 @@ class ShardedGraph:
                  degree_sum: Optional[str] = None):
         """`symmetric`: None = find out (an edge-multiset fingerprint of M against M^T); True / False skips
         the test (TextGCN graphs are symmetric by construction, text2graph.py:148-171).
-        `degree_sum`: "accurate" (float64 degree sums, symmetric association -- the default) or "reference" (PyG's
-        sequential fp32 sums in edge order and its association: the reference's bits; the operator is then not
-        bitwise symmetric and M^T gets its own operators).  None = the package default (pytextgcn_amd.set_degree_sum).
+        `degree_sum`: "reference" (PyG's sequential fp32 sums in edge order and its association: the reference's bits --
+        the package default; the operator is then not bitwise symmetric and M^T gets its own operators) or "accurate"
+        (float64 degree sums, symmetric association: one pair of operators serves M and M^T of a symmetric graph).
+        None = the package default (pytextgcn_amd.set_degree_sum).
         Either way the weights are bit for bit the single-device plan's of the same mode.
         Construction is COLLECTIVE: every rank of `group` must build the graph at the same time (the index lists of
         the halo exchange are swapped between the ranks)."""
@@ -425,10 +467,7 @@ class ShardedGraph:
         loops = (max(0, min(int(add_self_loops), 2)) if normalize else 0)
         self._dis = self._loop_w = None
         if normalize:
-            if degree_sum == "accurate":          # (test engines predate the argument; the default needs none)
-                self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops)
-            else:
-                self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops, degree_sum)
+            self._dis, self._loop_w = self.engine.gcn_norm(edge_index, edge_weight, num_nodes, loops, degree_sum)
         self._loops = loops
         self.symmetric = bool(symmetric) if symmetric is not None else \
             self._is_symmetric(edge_index, edge_weight)

@@ -3,7 +3,9 @@ each process its own NCCL_HOSTID makes them look like two hosts, so the pair tal
 (loopback) instead of P2P / shared memory.  Slow, but it is real RCCL with world size 2: the call sequences of
 pytextgcn_amd/sharded.py that gloo never takes (reduce_scatter_tensor, all_gather_into_tensor, batched send / recv).
 
-    python tools/experiments/rccl_one_gpu_probe.py          # parent: starts two ranks, bounded by a timeout
+    python tests/_rccl_one_gpu_probe.py          # parent: starts two ranks, bounded by a timeout
+
+Test infrastructure (tests/test_zz_gpu_sharded.py runs it once per session).
 """
 import os
 import subprocess
@@ -15,6 +17,7 @@ def rank_main(rank: int, world: int) -> None:
     os.environ["NCCL_HOSTID"] = f"tgcn-probe-{rank}"
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (what pytextgcn_amd.sharded.prepare_hsa_env decides)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)

@@ -5,7 +5,7 @@
   * the 1-D partition at size (c4 over 8 ranks with the word nodes as hubs; c5 over 8 ranks without hub structure):
     the local operators of the first and the last rank, cut exactly as the collective constructor cuts them
     (`ShardedGraph.for_rank`), against the oracle's operator entry by entry and row by row, the nnz balance, the index
-    lists of the halo exchange against a recomputation from the edge list, and the default mode's weights against the
+    lists of the halo exchange against a recomputation from the edge list, and the accurate mode's weights against the
     single-device plan's bit for bit.
 
 The reference is single-device (flat_amazon.py:84-86): the partition has nothing there to mirror, so the oracle of the
@@ -30,7 +30,7 @@ def test_config_c4_reference_order_mode_reproduces_the_oracles_weights_and_meets
     """`degree_sum="reference"`: PyG's CPU arithmetic (one fp32 accumulator per node, weights in edge order, the loop
     last; (dis[src] * w) * dis[dst]) -- what textgcn/lib/models.py:11-20 executes.  All 52 M weights of the c4 plan
     equal the oracle's bit for bit, M^T is stored (PyG's association is not symmetric), and the eval forward of
-    GCN(N -> 200 -> 64) over all 2 M rows is within 1e-5 of the fp32 oracle's network (the default mode is 1.3e-5 from
+    GCN(N -> 200 -> 64) over all 2 M rows is within 1e-5 of the fp32 oracle's network (the accurate mode is 1.3e-5 from
     it because the oracle's hub degrees are)."""
     N, F, C = c4case.N, 200, 64
     g = c4case.g
@@ -201,11 +201,11 @@ def test_config_c4_eight_rank_partition_first_and_last_rank_against_the_oracle(c
     assert abs(nnz[0] - nnz[W - 1]) <= 0.02 * max(nnz.values()), nnz
     _report("c4_partition_8_ranks", nnz_rank0=nnz[0], nnz_rank7=nnz[W - 1])
     del tgt, src, nw
-    # default mode: the weights of the partition are the single-device plan's, bit for bit (one degree routine)
-    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    # accurate mode: the weights of the partition are the single-device plan's, bit for bit (one degree routine)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")
     prp, pcol, pval = plan.export_csr()
     ptgt = torch.repeat_interleave(torch.arange(N, device=cuda), (prp[1:] - prp[:-1]).long())
-    sg = ShardedGraph.for_rank(g.edge_index, g.edge_attr, N, W, 0, hubs=hubs)
+    sg = ShardedGraph.for_rank(g.edge_index, g.edge_attr, N, W, 0, hubs=hubs, degree_sum="accurate")
     assert sg.symmetric and len(sg.dirs) == 1
     _assert_op_equals(sg.dirs[0].A, _expected_local_csr(sg, ptgt, pcol.long(), pval, "A"))
     _assert_op_equals(sg.dirs[0].B, _expected_local_csr(sg, ptgt, pcol.long(), pval, "B"))
@@ -249,7 +249,7 @@ def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5
     reference-order mode: both directions' operators equal the oracle's entries bit for bit; all its rows of M @ X at
     the class width against the C CSR oracle on the oracle's rows; sampled rows at h = 256.  Its halo lists against a
     recomputation from the edge list: the referenced columns (counts per owner, none twice, every column the operator
-    holds) and the slots it is asked for.  Rank 0 in the default mode with the symmetry fingerprint at size, weights
+    holds) and the slots it is asked for.  Rank 0 in the accurate mode with the symmetry fingerprint at size, weights
     bit for bit the single-device plan's."""
     N, W = c5case.N, 8
     g = c5case.g
@@ -312,10 +312,10 @@ def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5
     for dd in sg.dirs:
         dd.B.close()
     del sg, t_d, s_d, w_d, tgt, src, nw
-    # default mode, rank 0: symmetry decided by the fingerprint at size; weights = the single-device plan's bits
-    sg = ShardedGraph.for_rank(ei, g.edge_attr, N, W, 0, hubs=None)
+    # accurate mode, rank 0: symmetry decided by the fingerprint at size; weights = the single-device plan's bits
+    sg = ShardedGraph.for_rank(ei, g.edge_attr, N, W, 0, hubs=None, degree_sum="accurate")
     assert sg.symmetric and len(sg.dirs) == 1
-    plan = GraphPlan(ei, g.edge_attr, N)
+    plan = GraphPlan(ei, g.edge_attr, N, degree_sum="accurate")
     prp, pcol, pval = plan.export_csr()
     lo_hi = torch.nonzero(sg.part.owner == 0).flatten()
     ptgt = torch.repeat_interleave(torch.arange(N, device=cuda), (prp[1:] - prp[:-1]).long())

@@ -11,7 +11,7 @@ import torch
 from oracle import csr_oracle, gcn_oracle as O
 import pytextgcn_amd as pkg
 from pytextgcn_amd import _lib, synth
-from pytextgcn_amd.plan import GraphPlan, colsum
+from pytextgcn_amd.plan import GraphPlan, colsum, default_degree_sum
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -185,11 +185,25 @@ def test_gcn_norm_entry_point_matches_the_oracle(cuda, monkeypatch, add_loops, c
 
 
 def test_symmetric_graph_is_detected_and_shares_one_copy(cuda):
+    """The accurate mode (opt-in) keeps a symmetric graph's operator bitwise symmetric: one stored block serves M and
+    M^T.  The default (reference order: PyG's association (dis[s] * w) * dis[t]) rounds (i, j) and (j, i) apart, so M^T
+    is stored beside M -- the oracle's bits in both blocks."""
     g = synth.word_doc_graph(2000, 24000, seed=2, device=cuda)
-    plan = GraphPlan(g.edge_index, g.edge_attr, 2000)
-    assert plan.symmetric and plan.nnz == 24000 + 2000
+    plan = GraphPlan(g.edge_index, g.edge_attr, 2000, degree_sum="accurate")
+    assert plan.symmetric and plan.nnz == 24000 + 2000 and plan.query(_lib.Q_DEVICE_BYTES) > 0
     x = torch.randn(2000, 64, device=cuda)
     assert torch.equal(plan.spmm(x), plan.spmm(x, transpose=True))
+    ref = GraphPlan(g.edge_index, g.edge_attr, 2000)
+    assert ref.degree_sum == "reference" == default_degree_sum()
+    assert not ref.symmetric and ref.has_transpose and ref.nnz == ref.nnz_t == 24000 + 2000
+    assert ref.query(_lib.Q_DEVICE_BYTES) > 1.8 * plan.query(_lib.Q_DEVICE_BYTES)       # M^T is a stored block of its own
+    tgt, src, nw = O.normalized_coo(g.edge_index.cpu(), g.edge_attr.cpu(), 2000)
+    for tr, (a, b) in ((False, (tgt, src)), (True, (src, tgt))):
+        order = torch.argsort(a * 2000 + b, stable=True)
+        _, col, val = ref.export_csr(tr)
+        assert torch.equal(col.cpu().long(), b[order])
+        assert torch.equal(val.cpu().view(torch.int32), nw[order].view(torch.int32))
+    assert rel_err(ref.spmm(x, transpose=True), ref.spmm(x)) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------
@@ -559,17 +573,63 @@ def test_synthetic_graphs_do_not_depend_on_the_device_they_are_built_on(cuda):
 # ------------------------------------------------------------------------------------------------
 # benchmark-sized inputs (BASELINE.json configs c2 and c4)
 # ------------------------------------------------------------------------------------------------
-def test_config_c2_against_csr_oracle(cuda):
+def _oracle_csr_both_ways(ei, w, N):
+    """The oracle's normalised operator (oracle/gcn_oracle.py `normalized_coo`: PyG-1.6.3 gcn_norm, what the reference
+    runs at textgcn/lib/models.py:11-20) as CSR of M and of M^T, a row's entries by column with ties in edge order."""
+    tgt, src, nw = O.normalized_coo(ei.cpu(), w.cpu(), N)
+    out = []
+    for a, b in ((tgt, src), (src, tgt)):
+        order = torch.argsort(a * N + b, stable=True)
+        rp = torch.zeros(N + 1, dtype=torch.int64)
+        rp[1:] = torch.bincount(a, minlength=N).cumsum(0)
+        out.append((rp, b[order].to(torch.int32), nw[order].contiguous()))
+    return out
+
+
+def _reference_mode_whole_operator_check(cuda, plan, ei, w, N, F, case):
+    """The default (reference-order) plan against the oracle over the WHOLE operator: index arrays and all weights bit
+    for bit (both stored blocks), then ALL rows of M @ X + b and of M^T @ X against the C CSR oracle run on the
+    ORACLE's CSR, at BASELINE.json's 1e-5 in the max norm AND row by row."""
+    assert plan.degree_sum == "reference" and plan.has_transpose and not plan.symmetric
+    gen = torch.Generator(device=cuda).manual_seed(17)
+    x = torch.randn(N, F, device=cuda, generator=gen)
+    b = torch.randn(F, device=cuda, generator=gen)
+    xc, bc = x.cpu(), b.cpu()
+    for tr, (rp_ref, col_ref, val_ref) in zip((False, True), _oracle_csr_both_ways(ei, w, N)):
+        rp, col, val = plan.export_csr(tr)
+        assert torch.equal(rp.cpu().long(), rp_ref) and torch.equal(col.cpu(), col_ref)
+        n_diff = int((val.cpu().view(torch.int32) != val_ref.view(torch.int32)).sum())
+        assert n_diff == 0, (case, tr, n_diff)
+        del rp, col, val
+        got = plan.spmm(x, None if tr else b, transpose=tr)
+        want = csr_oracle.csr_spmm(rp_ref, col_ref, val_ref, xc, None if tr else bc, acc64=True)
+        e, e_row = rel_err(got, want), row_rel_err(got, want)
+        _report(case + ("_transposed" if tr else "_forward"), entries=int(val_ref.numel()), entries_differing_in_any_bit=n_diff,
+                all_rows_max_norm=e, all_rows_row_relative=e_row)
+        assert e < TOL and e_row < TOL, (case, tr, e, e_row)
+        del got, want
+
+
+def test_config_c2_reference_mode_whole_operator_against_the_oracle(cuda):
+    """BASELINE.json configs[1] (100 k nodes / 2 M edges, h = 200) in the package default mode."""
     N, E, F = 100_000, 2_000_000, 200
     g = synth.word_doc_graph(N, E, seed=44, device=cuda)
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    _reference_mode_whole_operator_check(cuda, plan, g.edge_index, g.edge_attr, N, F, "c2_reference_mode")
+
+
+def test_config_c2_accurate_mode_against_csr_oracle_and_float64_truth(cuda):
+    N, E, F = 100_000, 2_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")
     x = torch.randn(N, F, device=cuda)
     b = torch.randn(F, device=cuda)
     rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N)
     got, want = plan.spmm(x, b), csr_oracle.csr_spmm(rp, c, v, x.cpu(), b.cpu(), acc64=True)
     assert rel_err(got, want) < TOL
     # row by row the oracle's own fp32 normalisation is the looser side (its heavy rows carry a sequentially
-    # summed degree): 5e-5 here; the same rows against the float64 truth are held to 1e-5 below
+    # summed degree, which this opt-in mode deliberately does not reproduce): 5e-5 here; the same rows against the
+    # float64 truth are held to 1e-5 below
     assert row_rel_err(got, want) < 5e-5
     rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), N, transpose=True)
     got_t, want_t = plan.spmm(x, transpose=True), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)
@@ -586,8 +646,8 @@ def test_config_c2_against_csr_oracle(cuda):
 def test_config_c4_full_size_properties_and_sampled_rows(cuda):
     N, E, F = 2_000_000, 50_000_000, 200
     g = synth.word_doc_graph(N, E, seed=44, device=cuda, features="none")
-    plan = GraphPlan(g.edge_index, g.edge_attr, N)
-    assert plan.nnz == E + N and plan.symmetric
+    plan = GraphPlan(g.edge_index, g.edge_attr, N)              # the default mode: M^T is a stored block of its own
+    assert plan.nnz == E + N and plan.nnz_t == E + N and plan.has_transpose and not plan.symmetric
     gen = torch.Generator(device=cuda).manual_seed(1)
     x = torch.randn(N, F, device=cuda, generator=gen)
     y = torch.randn(N, F, device=cuda, generator=gen)
@@ -595,7 +655,7 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
     # linearity: M(2x - 3y) = 2Mx - 3My
     lin = plan.spmm(2 * x - 3 * y)
     assert rel_err(lin, 2 * mx - 3 * my) < TOL
-    # adjointness: <Mx, y> = <x, M^T y>  (transposed path; here M^T = M)
+    # adjointness: <Mx, y> = <x, M^T y>  (transposed path: the stored M^T block)
     lhs = (mx.double() * y.double()).sum().item()
     rhs = (x.double() * plan.spmm(y, transpose=True).double()).sum().item()
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3
@@ -739,8 +799,8 @@ def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda, c4case)
     ~10 M non-zeros) against the C CSR oracle run on the ORACLE's CSR."""
     N, E, F = 2_000_000, 50_000_000, 200
     g = c4case.g
-    plan = GraphPlan(g.edge_index, g.edge_attr, N)
-    assert plan.stats()["hot_rows"] > 0                         # the benchmark configuration of the kernels
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")    # (the default mode: tests/test_gpu_at_size.py)
+    assert plan.stats()["hot_rows"] > 0 and plan.symmetric      # the benchmark configuration of the kernels
     rp_ref, col_ref, val_ref, order = c4case.oracle_csr()
     rp, col, val = plan.export_csr()
     # which side of the heavy-row discrepancy is off: both against float64 (degrees summed in float64 on the host)
@@ -771,14 +831,18 @@ def test_config_c4_plan_against_oracle_normalisation_and_row_block(cuda, c4case)
     C = 64
     torch.manual_seed(7)
     model = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.5).to(cuda).float().eval()
-    with torch.no_grad():
-        model.layers[0].bias.normal_(0, 0.1)                      # zero biases (the init) would hide a bias bug
-        model.layers[1].bias.normal_(0, 0.1)
-        ar = torch.arange(N, device=cuda)
-        eye = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=cuda), (N, N)).coalesce()
-        logits = model(pkg.Data(x=eye, edge_index=g.edge_index, edge_attr=g.edge_attr)).cpu()
-        w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
-                                                     model.layers[1].weight, model.layers[1].bias))
+    prev = pkg.set_degree_sum("accurate")
+    try:
+        with torch.no_grad():
+            model.layers[0].bias.normal_(0, 0.1)                      # zero biases (the init) would hide a bias bug
+            model.layers[1].bias.normal_(0, 0.1)
+            ar = torch.arange(N, device=cuda)
+            eye = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=cuda), (N, N)).coalesce()
+            logits = model(pkg.Data(x=eye, edge_index=g.edge_index, edge_attr=g.edge_attr)).cpu()
+            w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
+                                                         model.layers[1].weight, model.layers[1].bias))
+    finally:
+        pkg.set_degree_sum(prev)
     # (1) against the FLOAT64 ground truth of the same network (float64 weights, float64 sums): the 1e-5 bar
     M64 = torch.sparse_csr_tensor(rp_ref, col_ref.long(), val64, (N, N))
     h1_t = torch.sparse.mm(M64, w1.double()) + b1.double()
@@ -964,9 +1028,22 @@ def test_fused_training_loop_tracks_the_oracle(cuda):
 # ------------------------------------------------------------------------------------------------
 # dense X @ W on the fp32 matrix cores
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("amsgrad,wd,hidden,asym", [(True, 0.0, 200, False), (False, 0.01, 132, False),
-                                                    (True, 0.0, 260, False), (True, 0.0, 200, True)])
-def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, amsgrad, wd, hidden, asym):
+@pytest.fixture
+def degree_mode(request):
+    """Package default normalisation mode for the duration of one test (None = leave the default: "reference")."""
+    mode = getattr(request, "param", None)
+    prev = pkg.set_degree_sum(mode) if mode else None
+    pkg.clear_plan_cache()
+    yield mode or default_degree_sum()
+    if prev:
+        pkg.set_degree_sum(prev)
+    pkg.clear_plan_cache()
+
+
+@pytest.mark.parametrize("amsgrad,wd,hidden,asym,degree_mode", [
+    (True, 0.0, 200, False, None), (False, 0.01, 132, False, None), (True, 0.0, 260, False, None), (True, 0.0, 200, True, None),
+    (True, 0.0, 200, False, "accurate")], indirect=["degree_mode"])      # accurate: M^T = M, the shared block feeds the update
+def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, amsgrad, wd, hidden, asym, degree_mode):
     """optim.Adam.fuse_into_backward(W1): the rows of dW1 = M^T dH1 are spent on Adam inside tgcn_spmm_adam
     (row blocks, long-row segments through k_spmm_fix, the dense hot block).  After several epochs of the
     loop of flat_amazon.py:99-106 every parameter and every optimizer state must equal, BIT FOR BIT, those of
@@ -986,7 +1063,7 @@ def test_w1_update_fused_into_the_backward_spmm_is_bitwise_the_plain_step(cuda, 
         g = synth.word_doc_graph(N, 160000, seed=23, n_classes=C)
     gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
     plan = GraphPlan(gd.edge_index, gd.edge_attr, N)
-    assert plan.symmetric != asym
+    assert plan.degree_sum == degree_mode and plan.symmetric == (degree_mode == "accurate" and not asym)
     assert plan.stats()["long_rows"] > 0 and plan.stats()["hot_rows"] > 0      # every epilogue is exercised
     torch.manual_seed(11)
     base = pkg.GCN(N, C, n_hidden_gcn=hidden, dropout=0.0)
@@ -1365,20 +1442,21 @@ def test_config_c3_sized_layer_two_runs_on_the_hand_written_kernels(cuda, monkey
     go = torch.randn(N, C, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
     out.backward(go)
     monkeypatch.setattr(torch, "matmul", real)
-    # float64 reference of the same network from the plan's own operator
-    plan = model.layers[0].plan(g.x, g.edge_index, g.edge_attr)
-    rp, col, val = plan.export_csr()
-    M = torch.sparse_csr_tensor(rp.long(), col.long(), val.double(), (N, N))
+    # float64 reference of the same network on the ORACLE's operator (oracle/gcn_oracle.py's normalisation of the same
+    # edge list: M and M^T as the oracle holds them -- a normalisation error of the plan would show here)
+    (rp, col, val), (rpt, colt, valt) = _oracle_csr_both_ways(g.edge_index, g.edge_attr, N)
+    M = torch.sparse_csr_tensor(rp.to(cuda), col.long().to(cuda), val.double().to(cuda), (N, N))
+    Mt = torch.sparse_csr_tensor(rpt.to(cuda), colt.long().to(cuda), valt.double().to(cuda), (N, N))
     W1, b1 = model.layers[0].weight.detach().double(), model.layers[0].bias.detach().double()
     W2, b2 = model.layers[1].weight.detach().double(), model.layers[1].bias.detach().double()
     H1 = M @ W1 + b1
     ref = M @ (H1 @ W2) + b2
-    assert rel_err(out.detach(), ref.float()) < TOL
-    dXW2 = M.t().to_sparse_csr() @ go.double() if not plan.symmetric else M @ go.double()
+    assert rel_err(out.detach(), ref.float()) < TOL and row_rel_err(out.detach(), ref.float()) < TOL
+    dXW2 = Mt @ go.double()
     assert rel_err(model.layers[1].weight.grad, (H1.t() @ dXW2).float()) < TOL
     dH1 = dXW2 @ W2.t()
     assert rel_err(model.layers[0].bias.grad, dH1.sum(0).float()) < 2e-5
-    assert rel_err(model.layers[0].weight.grad, (M @ dH1).float()) < TOL
+    assert rel_err(model.layers[0].weight.grad, (Mt @ dH1).float()) < TOL
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1395,11 +1473,22 @@ def _sampled_row_check(plan, x, y, rows, tol=TOL):
 
 def test_config_c3_dbpedia_shaped_graph(cuda):
     """~1 M nodes with a 30 k vocabulary (flat_dbpedia.py: min_df=100, max_df=.4 keep the vocabulary
-    small), h = 200; the real DBpedia CSVs are not in the reference tree."""
+    small), h = 200; the real DBpedia CSVs are not in the reference tree.  The package default (reference-order) mode
+    over the WHOLE operator: all 25 M weights of both stored blocks bit for bit the oracle's, all 1 M rows of M @ X + b
+    and of M^T @ X against the C CSR oracle on the oracle's CSR at 1e-5, max norm and row by row."""
     N, E, F = 1_000_000, 24_000_000, 200
     g = synth.word_doc_graph(N, E, seed=44, device=cuda, vocab_frac=0.03, doc_word_share=0.9, features="none")
     assert g.n_vocab == 30_000
     plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    assert plan.nnz == E + N
+    _reference_mode_whole_operator_check(cuda, plan, g.edge_index, g.edge_attr, N, F, "c3_reference_mode")
+
+
+def test_config_c3_dbpedia_shaped_graph_accurate_mode(cuda):
+    """The opt-in accurate mode on the same graph: a row block against the oracle, sampled rows against float64."""
+    N, E, F = 1_000_000, 24_000_000, 200
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, vocab_frac=0.03, doc_word_share=0.9, features="none")
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")
     assert plan.symmetric and plan.nnz == E + N
     gen = torch.Generator(device=cuda).manual_seed(3)
     x = torch.randn(N, F, device=cuda, generator=gen)
@@ -1421,7 +1510,7 @@ def test_config_c5_power_law_graph_h256(cuda, c5case):
     N, E, F = 8_000_000, 200_000_000, 256
     g = c5case.g
     assert g.edge_index.shape == (2, E)
-    plan = GraphPlan(g.edge_index, g.edge_attr, N)
+    plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="accurate")
     assert plan.symmetric and plan.nnz == E + N
     gen = torch.Generator(device=cuda).manual_seed(5)
     x = torch.randn(N, F, device=cuda, generator=gen)
@@ -1446,6 +1535,28 @@ def test_config_c5_power_law_graph_h256(cuda, c5case):
     _assert_csr_equal(rp[:R + 1], col[:e_r], val[:e_r], rp_ref, src[:nb], nw[:nb], truth=w64[:nb], case="c5_weights")
     ref = csr_oracle.csr_spmm(rp_ref, src[:nb], nw[:nb], x.cpu(), acc64=True)
     assert rel_err(y[:R], ref) < TOL
+    # the package DEFAULT (reference-order) mode on the same block: the weights are the oracle's bit for bit, and the rows
+    # meet 1e-5 against it in the max norm and row by row (the heaviest rows of the power law sit in this block's picks)
+    plan_r = GraphPlan(g.edge_index, g.edge_attr, N)
+    assert plan_r.degree_sum == "reference" and plan_r.has_transpose and not plan_r.symmetric
+    rp_r, col_r, val_r = plan_r.export_csr()
+    assert torch.equal(rp_r[:R + 1].cpu().long(), rp_ref) and torch.equal(col_r[:e_r].cpu(), src[:nb])
+    assert torch.equal(val_r[:e_r].cpu().view(torch.int32), nw[:nb].view(torch.int32))
+    for r in heavy.tolist():
+        s_, e_ = rp_r[r].item(), rp_r[r + 1].item()
+        assert torch.equal(val_r[s_:e_].cpu().view(torch.int32), nw[tgt == r].view(torch.int32)), r
+    del rp_r, col_r, val_r
+    y_r = plan_r.spmm(x)
+    e_blk, e_blk_row = rel_err(y_r[:R], ref), row_rel_err(y_r[:R], ref)
+    _report("c5_reference_mode_row_block", rows=R, max_norm=e_blk, row_relative=e_blk_row)
+    assert e_blk < TOL and e_blk_row < TOL, (e_blk, e_blk_row)
+    z_r = torch.randn(N, 8, device=cuda, generator=gen)
+    u_r = torch.randn(N, 8, device=cuda, generator=gen)
+    lhs = (plan_r.spmm(z_r).double() * u_r.double()).sum().item()           # <M z, u> = <z, M^T u>: the stored M^T block
+    rhs = (z_r.double() * plan_r.spmm(u_r, transpose=True).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-4
+    plan_r.close()
+    del plan_r, y_r, z_r, u_r
     xc = x.cpu()
     for r in heavy.tolist():
         if r < R:
@@ -1949,7 +2060,7 @@ def test_fused_w1_update_refuses_a_second_backward_before_step(cuda):
 def test_dense_hot_block_is_chosen_for_the_benchmark_shapes_only_when_it_pays(cuda):
     g = synth.word_doc_graph(100_000, 2_000_000, seed=44, device=cuda, features="none")     # c2
     p = GraphPlan(g.edge_index, g.edge_attr, 100_000)
-    assert p.stats()["hot_rows"] == 32 and p.symmetric
+    assert p.stats()["hot_rows"] == 32
     x = torch.randn(100_000, 200, device=cuda)
     rp, c, v = csr_oracle.normalized_csr(g.edge_index.cpu(), g.edge_attr.cpu(), 100_000)
     assert rel_err(p.spmm(x), csr_oracle.csr_spmm(rp, c, v, x.cpu(), acc64=True)) < TOL

@@ -73,6 +73,12 @@ def test_world4_hub_partition():
     run(4, ["wordoc"])
 
 
+def test_world2_accurate_mode_shares_one_operator_pair_between_m_and_its_transpose():
+    """degree_sum="accurate" (opt-in): a symmetric graph's operator stays bitwise symmetric, so the partition builds
+    one (A_r, B_r) pair; the package default (reference order) builds two."""
+    run(2, ["wordoc@accurate", "asym@accurate"])
+
+
 def test_world3_pairwise_exchange(monkeypatch):
     """TGCN_EXCHANGE=p2p: the same hub exchange as batched send/recv + all-to-all with a local sum."""
     monkeypatch.setenv("TGCN_EXCHANGE", "p2p")            # inherited by the spawned ranks

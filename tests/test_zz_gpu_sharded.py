@@ -53,25 +53,41 @@ def _n_gpus():
 _RCCL_SHARED = {}
 
 
+# what RCCL prints when it REFUSES ranks that share a device or cannot use the loopback interface: the only outcomes of the
+# probe that mean "this box cannot do it" (skip).  Anything else that goes wrong in the probe -- a timeout, a signal, an
+# abort, a wrong result -- is a failure of RCCL on the box and FAILS the tests that depend on it.
+_RCCL_REFUSALS = ("duplicate gpu detected", "no socket interface found", "no interface found", "bootstrap : no socket",
+                  "failed to find a usable interface")
+
+
 def _rccl_ranks_can_share_the_gpu():
-    """Two RCCL ranks on one GPU need loopback sockets and an RCCL that honours NCCL_HOSTID: probed ONCE
-    (tools/experiments/rccl_one_gpu_probe.py: init + all-reduce / all-gather / reduce-scatter / send-recv, bounded); a
-    box where that does not work skips the shared-GPU RCCL tests instead of failing them -- they test the product's
-    call sequences under RCCL, not the box's networking."""
+    """Two RCCL ranks on one GPU need loopback sockets and an RCCL that honours NCCL_HOSTID: probed
+    ONCE per session (tests/_rccl_one_gpu_probe.py: init + all-reduce / all-gather / reduce-scatter / send-recv, bounded).
+    A box whose RCCL refuses the arrangement (the signatures above) skips the shared-GPU RCCL tests -- they test the
+    product's call sequences under RCCL, not the box's networking; a probe that hangs, dies or computes a wrong value
+    fails them, with its output attached."""
     if "ok" not in _RCCL_SHARED:
         import subprocess
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        here = os.path.dirname(os.path.abspath(__file__))
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env.update(PROBE_BUDGET_S="90", MASTER_PORT=str(free_port()))
         try:
-            res = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "rccl_one_gpu_probe.py")],
+            res = subprocess.run([sys.executable, os.path.join(here, "_rccl_one_gpu_probe.py")],
                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
+            text = res.stdout.decode("utf-8", "replace")
             _RCCL_SHARED["ok"] = res.returncode == 0
-            _RCCL_SHARED["why"] = res.stdout.decode()[-400:]
-        except subprocess.TimeoutExpired:
-            _RCCL_SHARED["ok"], _RCCL_SHARED["why"] = False, "the probe did not finish in 150 s"
-    if not _RCCL_SHARED["ok"]:
-        pytest.skip("RCCL ranks cannot share the GPU on this box: " + _RCCL_SHARED["why"])
+            _RCCL_SHARED["refused"] = res.returncode != 0 and res.returncode != 124 and \
+                any(sig in text.lower() for sig in _RCCL_REFUSALS)
+            _RCCL_SHARED["why"] = f"exit {res.returncode}: " + text[-1200:]
+        except subprocess.TimeoutExpired as e:
+            _RCCL_SHARED["ok"], _RCCL_SHARED["refused"] = False, False
+            _RCCL_SHARED["why"] = "the probe did not finish in 150 s: " + (e.stdout or b"").decode("utf-8", "replace")[-1200:]
+    if _RCCL_SHARED["ok"]:
+        return
+    if _RCCL_SHARED["refused"]:
+        pytest.skip("RCCL refuses ranks that share the GPU on this box: " + _RCCL_SHARED["why"][-400:])
+    pytest.fail("the RCCL probe (two ranks on one GPU over loopback) hung, died or computed a wrong value -- not a "
+                "refusal signature:\n" + _RCCL_SHARED["why"])
 
 
 @pytest.mark.parametrize("exchange", ["collective", "p2p", "halo"])
