@@ -257,8 +257,68 @@ def distributed_parity(sg, g, N, F, x_local, gout_local, bias, dev, dist, mode):
         del full, ref, mine
     out["ok"] = bool(max(errs) < 1e-5)
     out["rows_checked"] = N
+    # the SAME step on ONE device, timed here on this rank's GPU with the whole-graph plan that was just checked against
+    # (every rank times its own card at the same time; the slowest is reported): the denominator of `scaling_model`
+    xs = torch.randn(N, F, device=dev)
+    ys = torch.empty(N, F, device=dev)
+    for _ in range(2):
+        plan.spmm(xs, bias, out=ys), plan.spmm(xs, None, transpose=True, out=ys)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        plan.spmm(xs, bias, out=ys), plan.spmm(xs, None, transpose=True, out=ys)
+    ev[1].record()
+    torch.cuda.synchronize()
+    t1 = torch.tensor([ev[0].elapsed_time(ev[1]) / 5], device=dev, dtype=torch.float64)
+    dist.all_reduce(t1, op=dist.ReduceOp.MAX, group=sg.group)
+    out["single_device_ms_per_step"] = t1.item()
+    del xs, ys
     out["seconds"] = round(time.perf_counter() - t0, 2)
     return out
+
+
+XGMI_LINK_GBPS = 153.0      # per link and direction (task statement / MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+
+
+def scaling_model(world, ms_per_step, parity, diag, sg, F):
+    """What the link arithmetic allows, next to what was measured -- so that a scaling line can be read without opening
+    DESIGN.md.  All times are per bench step (forward + transposed SpMM at width F) on this node:
+      compute    the rank's local operators alone (A_r and B_r, both directions; max over ranks);
+      exchange   the two collectives of each SpMM alone (all-gather + reduce-scatter of the hub block, measured here);
+      hidden / exposed   the step time if the exchange overlapped the compute completely / not at all."""
+    if not diag or not parity or "single_device_ms_per_step" not in parity:
+        return None
+
+    def ms(key):
+        v = diag.get(key)
+        return v.get("max_ms") if isinstance(v, dict) else None
+    a, b = ms("local_A_hub_rows_x_own_regulars") or 0.0, ms("local_B_own_rows")
+    ag, rs = ms("all_gather_into_tensor"), ms("reduce_scatter_tensor")
+    if b is None or ag is None or rs is None:
+        return None
+    t1 = parity["single_device_ms_per_step"]
+    has_rs = sg.rp > 0
+    compute = 2.0 * (a + b)
+    exchange = 2.0 * (ag + (rs if has_rs else 0.0))
+    link_bytes = sg.hp * F * 4                       # what one rank sends to ONE peer in one collective (its own link)
+    link_floor = 2.0 * (2 if has_rs else 1) * link_bytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+    return {
+        "single_device_ms_per_step": t1, "ms_per_step_measured": ms_per_step, "speedup_measured": t1 / ms_per_step,
+        "compute_ms_per_step": compute, "compute_scaling": t1 / compute if compute else None,
+        "exchange_ms_per_step_measured_alone": exchange,
+        "ms_per_step_if_exchange_fully_hidden": max(compute, exchange),
+        "ms_per_step_if_exchange_fully_exposed": compute + exchange,
+        "speedup_if_exchange_fully_hidden": t1 / max(compute, exchange),
+        "speedup_if_exchange_fully_exposed": t1 / (compute + exchange),
+        "collectives_per_step": 2 * (2 if has_rs else 1),
+        "bytes_per_link_and_collective": link_bytes,
+        "link_GBps_assumed": XGMI_LINK_GBPS,
+        "exchange_ms_per_step_at_link_peak": link_floor,
+        "speedup_if_exchange_at_link_peak_and_exposed": t1 / (compute + link_floor),
+        "note": "a 1-D row partition with the word block replicated exchanges 2 x |hubs| x F floats per SpMM whatever the "
+                "number of ranks, while the compute shrinks with 1 / W: the SpMM-pair metric is exchange-bound at 8 ranks "
+                "unless the collectives hide behind the local operators completely (north_star's >= 6x needs that); the "
+                "training step additionally has the narrow exchange (exchange_floats_per_hub_row_and_step)"}
 
 
 _DEVICE_ERROR_WORDS = ("hip error", "hiperror", "hsa_status", "hsa error", "memory access fault", "illegal memory access",
@@ -614,7 +674,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     return sorted(times)[len(times) // 2]
 
 
-def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False):
+def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False, narrow=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
     summed with one all-reduce; predictions of the owned rows go to the host."""
@@ -629,7 +689,8 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
     val_l = sg.scatter_rows(is_doc & (u >= 0.8) & (u < 0.9))
     del y_full, u
     pkg.enable_activation_reuse(reuse)
-    model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5).to(dev)
+    # narrow: hub rows cross the links at the class width where the activation-free network allows (pytextgcn_amd/narrow.py)
+    model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5, narrow_exchange=narrow).to(dev)
     with torch.no_grad():
         model.weights[0].uniform_(-0.0017, 0.0017)            # glorot bound of an N x h matrix
     opt = pkg.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
@@ -718,6 +779,37 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10):
     out["halo_gather_referenced_rows_only"] = phase(halo_gather)
     out["rows_received_per_spmm"] = sg.exchange_rows()
     out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
+
+    # HOST side of one distributed SpMM: the time the Python thread needs to ENQUEUE it (ctypes launches, the async
+    # collectives, the closures) with the device free to run behind -- no synchronisation inside the loop, median of 50.
+    # If this approaches the device time of the step the device starves (at 8 ranks the step is ~0.6-0.8 ms).
+    def host_enqueue(fn, n=50):
+        for _ in range(3):
+            fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            if len(ts) % 10 == 0:
+                torch.cuda.synchronize()          # keep the queue from growing without bound (outside the timed calls)
+        torch.cuda.synchronize()
+        med = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        return round(med.item(), 4)
+    try:
+        host_ms = host_enqueue(lambda: sg.spmm(x, None))
+        dev_ms = out["whole_spmm_overlapped"].get("max_ms")
+        out["host_enqueue_ms_per_spmm"] = host_ms
+        out["host_enqueue_over_device_time"] = round(host_ms / dev_ms, 3) if dev_ms else None
+        out["host_enqueue_local_launches_only_ms"] = host_enqueue(
+            lambda: sg.local_step(d0, x, None, sg._gather_buffer(x, False), rs_out)) if A is not None else None
+    except Exception as e:                           # noqa: BLE001 - same rule as `phase`
+        if W > 1 or is_device_error(e):
+            raise
+        out["host_enqueue_ms_per_spmm"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 
@@ -1044,6 +1136,7 @@ def main():
                            lambda: distributed_parity(sg, g, N, F, x, gout, bias, dev, dist, headline_mode))
 
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
+    epoch_ms_narrow = None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = secondary("epoch_ms_fused", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist))
@@ -1053,6 +1146,9 @@ def main():
                                 lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True))
         epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
                                       lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True))
+        if sg.rp > 0 and C % 4 == 0 and F % 4 == 0:
+            epoch_ms_narrow = secondary("epoch_ms_fused_w1_reuse_narrow_exchange",
+                                        lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True))
     diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
         if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
@@ -1069,6 +1165,8 @@ def main():
         epoch_ms_split = secondary("epoch_ms_fused_w1_reuse_split_bf16_gemms",
                                    lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))
 
+    model_of_scaling = scaling_model(world, elapsed / args.steps * 1e3, parity, diagnostics, sg, F) \
+        if parallelism != "single" else None
     rccl = rccl_info(dist, backend, world, rank, local_rank, dev)        # collective: every rank takes part
     rccl["hsa_env"] = hsa_env
     copy_gbps = device_copy_gbps(dev) if rank == 0 else None
@@ -1179,6 +1277,16 @@ def main():
             # the same with the layer-2 products in the opt-in split-bf16 mode (dense.enable_split_gemms: fp32-accurate,
             # NOT bit-equal to the fp32 FMA chain -- reported apart for that reason)
             "epoch_ms_fused_w1_reuse_split_bf16_gemms": epoch_ms_split,
+            # N > 1, opt-in, fp32-equal (1e-5) but not bit-equal to the plain exchange: ShardedGCN(narrow_exchange=True) --
+            # two of the four width-h collectives of a training step travel at the class width (pytextgcn_amd/narrow.py)
+            "epoch_ms_fused_w1_reuse_narrow_exchange": epoch_ms_narrow,
+            "exchange_floats_per_hub_row_and_step": None if parallelism == "single" else {
+                "plain": {"train": 4 * F + 4 * C, "eval": 2 * F + 2 * C},
+                "narrow": {"train": 2 * F + 6 * C, "eval": F + 3 * C},
+                "hub_rows": int(sg.world * sg.hp), "bytes_per_float": 4,
+                "note": "each collective moves (W - 1) / W of the [W * hp] hub block per rank; an all-reduce counts as "
+                        "reduce-scatter + all-gather; one epoch = one training step + one eval forward"},
+            "scaling_model": model_of_scaling,
             # N > 1: phase-by-phase timing of one distributed SpMM on this node (not part of the metric)
             "exchange_diagnostics": diagnostics,
             "exchange_selection": exchange_selection,

@@ -64,16 +64,24 @@ class _row_keys:
         return False
 
 
-def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_mask: bool = False, keys=None):
+def gemm_nn(a: Tensor, b: Tensor, p: float = 0.0, seed: Tensor = None, record_mask: bool = False, keys=None,
+            out: Tensor = None):
     """a [N, k] @ b [k, n]; with `seed`: dropout(a, p) @ b, the mask regenerated from the seed.
     `record_mask` (with `seed`): returns (product, mask) where `mask` is the kernel's record of its keep decisions
     ([N, words] int32, `tgcn_gemm_nn_dropout_mask`) for `gemm_tn(..., mask=...)`, or None when a product of this shape
-    cannot record it.  `keys` = (split, key0, key1): which mask row a row of `a` is (see `_row_keys`)."""
+    cannot record it.  `keys` = (split, key0, key1): which mask row a row of `a` is (see `_row_keys`).  `out`: a
+    float32 [N, n] result buffer of the caller's (unit column stride, rows 16-byte aligned)."""
     lib = _lib.load()
     a, b = _rowmajor4(a), b.contiguous()
     N, k = a.shape
     n = b.size(1)
-    c = alloc_padded(N, n, a.device)          # rows of 4 j floats (zero pad columns): the propagate step takes it as it is
+    if out is None:
+        c = alloc_padded(N, n, a.device)      # rows of 4 j floats (zero pad columns): the propagate step takes it as it is
+    else:
+        c = out
+        if c.shape != (N, n) or c.dtype != torch.float32 or c.device != a.device or (N and c.stride(1) != 1) \
+                or c.stride(0) % 4 != 0 or c.data_ptr() % 16 != 0:
+            raise ValueError("gemm_nn: `out` must be a float32 [N, n] device tensor with unit column stride and 16-byte rows")
     args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), N, k, n)
     mask = None
     if seed is None:
@@ -183,12 +191,12 @@ class _XWDropout(torch.autograd.Function):
     second time -- the same decisions, so the same bits in the result."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, w: Tensor, p: float, seed: Tensor):
-        ctx.p = p
+    def forward(ctx, x: Tensor, w: Tensor, p: float, seed: Tensor, keys=None):
+        ctx.p, ctx.keys = p, keys
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            out, mask = gemm_nn(x.detach(), w.detach(), p, seed, record_mask=True)
+            out, mask = gemm_nn(x.detach(), w.detach(), p, seed, record_mask=True, keys=keys)
         else:
-            out, mask = gemm_nn(x.detach(), w.detach(), p, seed), None
+            out, mask = gemm_nn(x.detach(), w.detach(), p, seed, keys=keys), None
         ctx.has_mask = mask is not None
         ctx.save_for_backward(x, w, seed, *([mask] if mask is not None else []))
         return out
@@ -197,9 +205,10 @@ class _XWDropout(torch.autograd.Function):
     def backward(ctx, g: Tensor):
         x, w, seed = ctx.saved_tensors[:3]
         mask = ctx.saved_tensors[3] if ctx.has_mask else None
-        dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True, mask=mask) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
-        dw = gemm_tn(x, g, ctx.p, seed, mask) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
-        return dx, dw, None, None
+        k = ctx.keys
+        dx = gemm_nt(g, w, ctx.p, seed, note_colsums=True, mask=mask, keys=k) if ctx.needs_input_grad[0] else None     # mask * (g @ w^T) / (1 - p)
+        dw = gemm_tn(x, g, ctx.p, seed, mask, keys=k) if ctx.needs_input_grad[1] else None     # dropout(x)^T @ g
+        return dx, dw, None, None, None
 
 
 def new_seed(device) -> Tensor:
@@ -208,13 +217,14 @@ def new_seed(device) -> Tensor:
     return torch.empty(1, dtype=torch.int64, device=device).random_()
 
 
-def xw_dropout(x: Tensor, w: Tensor, p: float, seed: Tensor = None) -> Tensor:
+def xw_dropout(x: Tensor, w: Tensor, p: float, seed: Tensor = None, keys=None) -> Tensor:
     """dropout(x, p) @ w (training-mode inverted dropout, textgcn/lib/models.py:23 followed by the next
-    layer's x @ W) as ONE pass over x."""
+    layer's x @ W) as ONE pass over x.  `keys` = (split, key0, key1): which row of the mask a row of x is (the 1-D
+    partition keys a node's mask by its position in the partition, not by the local row: `tgcn_set_dropout_row_keys`)."""
     if p <= 0.0:
         return xw(x, w)
     _require(x, w)
-    return _XWDropout.apply(x, w, float(p), new_seed(x.device) if seed is None else seed)
+    return _XWDropout.apply(x, w, float(p), new_seed(x.device) if seed is None else seed, keys)
 
 
 def xw(x: Tensor, w: Tensor) -> Tensor:

@@ -100,7 +100,7 @@ class Adam(Optimizer):
         return True
 
     @torch.no_grad()
-    def _fused_update_sharded(self, p, sg, g) -> bool:
+    def _fused_update_sharded(self, p, sg, g, hub_block=None, pending=None) -> bool:
         """The same for a rank's row shard of W1 in the 1-D partition (pytextgcn_amd.sharded._ShardedPropagate): the
         regular rows are updated inside the backward SpMM (split operand), the hub slice by one Adam pass once its
         gradient rows are reduced.  False = not applicable (caller takes the plain path)."""
@@ -133,7 +133,7 @@ class Adam(Optimizer):
                 _lib.check(lib.tgcn_adam_step(pr.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                                               vm.data_ptr() if vm is not None else None, pr.numel(), *hyper,
                                               _stream_ptr(p.device)))
-        sg.spmm_adam_w1(g, adam)
+        sg.spmm_adam_w1(g, adam, hub_block=hub_block, pending=pending)
         torch.autograd.graph.increment_version(p)
         return True
 

@@ -168,6 +168,24 @@ class HipEngine:
         from . import dense
         return dense.xw_dropout(x, w, p)      # dropout fused into the three GEMMs (dropped activation never stored)
 
+    # the three layer-2 products one by one (pytextgcn_amd/narrow.py composes them itself); `keys`: which mask row a
+    # matrix row is (tgcn_set_dropout_row_keys)
+    def gemm_nn(self, a, b, p=0.0, seed=None, record_mask=False, keys=None, out=None):
+        from . import dense
+        return dense.gemm_nn(a, b, p, seed, record_mask=record_mask, keys=keys, out=out)
+
+    def gemm_nt(self, a, b, p=0.0, seed=None, mask=None, keys=None):
+        from . import dense
+        return dense.gemm_nt(a, b, p, seed, note_colsums=True, mask=mask, keys=keys)
+
+    def gemm_tn(self, a, g, p=0.0, seed=None, mask=None, keys=None):
+        from . import dense
+        return dense.gemm_tn(a, g, p, seed, mask, keys=keys)
+
+    def xw_dropout_keyed(self, x: Tensor, w: Tensor, p: float, seed: Tensor, keys) -> Tensor:
+        from . import dense
+        return dense.xw_dropout(x, w, p, seed=seed, keys=keys)
+
     def masked_ce(self, logits: Tensor, y: Tensor, mask: Tensor, count: int, return_pred: bool = False):
         from .functional import masked_cross_entropy
         return masked_cross_entropy(logits, y, mask, count=count, return_pred=return_pred)
@@ -479,6 +497,7 @@ class ShardedGraph:
         self.rs_chunks = 1
         self._xbuf = {}
         self._stage = {}
+        self._recv = {}
 
     @property
     def ops(self):
@@ -728,14 +747,23 @@ class ShardedGraph:
         # the halo form writes only the rows the direction's B_r references: M and M^T of an asymmetric graph read
         # different rows, so each direction keeps its own block (a row left over from the other direction would be
         # multiplied by a zero weight of the dense hot block -- harmless only while it is finite)
-        key = self._xbuf_key(x_local, halo, d)
+        return self._operand_buffer(self._xbuf_key(x_local, halo, d))[:self.world * self.hp]
+
+    def _operand_buffer(self, key) -> Tensor:
+        """The whole buffer behind `_gather_buffer` (key = `_xbuf_key`): [W * hp (+ rp at narrow widths), F]."""
         xbuf = self._xbuf.get(key)
         if xbuf is None:
+            F, dtype, device, halo = key[:4]
             make = torch.zeros if halo else torch.empty
             rows = self.world * self.hp + (self.rp if F <= self._NARROW else 0)
-            xbuf = make(rows, F, dtype=x_local.dtype, device=x_local.device)
+            xbuf = make(rows, F, dtype=dtype, device=device)
             self._xbuf[key] = xbuf
-        return xbuf[:self.world * self.hp]
+        return xbuf
+
+    def operand_buffer(self, F: int, device, dtype=torch.float32) -> Tensor:
+        """The operand buffer of width F of the collective / pairwise forms (the one `spmm` gathers into): rows [0, W * hp)
+        the hub block, at narrow widths followed by rp rows for the rank's own regular rows."""
+        return self._operand_buffer((F, dtype, device, False, 0))
 
     def _whole_operand(self, d: _Direction, x_local: Tensor) -> Optional[Tensor]:
         """[gathered hubs ; own regular rows] as one tensor when the width calls for it (see _gather_buffer)."""
@@ -762,7 +790,7 @@ class ShardedGraph:
         # halo: only the rows somebody reads travel
         xbuf = self._gather_buffer(x_local, True, d)
         pack = self._rows_gather(shard, d.send_slots)
-        recv, work = self._all_to_all_v(pack, d.need_counts_l, d.send_counts_l, direct)
+        recv, work = self._all_to_all_v(pack, d.need_counts_l, d.send_counts_l, direct, role="gather")
 
         def finish():
             work.wait()
@@ -780,12 +808,26 @@ class ShardedGraph:
         else:
             y.index_copy_(0, idx, x)
 
-    def _all_to_all_v(self, src: Tensor, out_sizes, in_sizes, direct: bool):
+    def _recv_buffer(self, role, shape, dtype, device) -> Tensor:
+        """Receive buffer of one collective of the distributed SpMM, kept per (role, shape): `role` names the collective
+        inside one SpMM (the gather, the reduce of chunk k), so two transfers in flight never share one; consecutive
+        SpMMs reuse it in stream order (the consumer of call n is enqueued before the collective of call n + 1, and the
+        communicator's stream waits for the caller's at enqueue)."""
+        key = (role, tuple(shape), dtype, device)
+        buf = self._recv.get(key)
+        if buf is None:
+            if len(self._recv) >= 64:
+                self._recv.clear()
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            self._recv[key] = buf
+        return buf
+
+    def _all_to_all_v(self, src: Tensor, out_sizes, in_sizes, direct: bool, role="a2a"):
         """all_to_all_single with split sizes (rows); device tensors over a host-serviced backend go through pinned
         host memory with blocking copies (see `_stream_ordered`).  Returns (received rows, work)."""
         shape = (sum(out_sizes),) + tuple(src.shape[1:])
         if direct:
-            dst = torch.empty(shape, dtype=src.dtype, device=src.device)
+            dst = self._recv_buffer(role, shape, src.dtype, src.device)
             return dst, dist.all_to_all_single(dst, src, out_sizes, in_sizes, group=self.group, async_op=True)
         h_src = self._host_stage("a2av_src", src.shape, src.dtype)
         h_dst = self._host_stage("a2av_dst", shape, src.dtype)
@@ -808,7 +850,7 @@ class ShardedGraph:
             else:
                 y_hub[ch.k::K] += acc[:ch.n_own]
         if self.exchange == "collective":
-            out = torch.empty(ck, F, dtype=partial.dtype, device=partial.device)
+            out = self._recv_buffer(("rs", K, ch.k), (ck, F), partial.dtype, partial.device)
             work = dist.reduce_scatter_tensor(out, partial, group=self.group, async_op=True)
 
             def finish(y_hub):
@@ -818,7 +860,7 @@ class ShardedGraph:
         ranked = getattr(self.engine, "reduce_ranked_", None) if partial.is_cuda else None
         if self.exchange == "p2p":
             sizes = [ck] * W
-            recv, work = self._all_to_all_v(partial, sizes, sizes, direct)
+            recv, work = self._all_to_all_v(partial, sizes, sizes, direct, role=("rs", K, ch.k))
 
             def finish(y_hub):
                 work.wait()
@@ -832,7 +874,7 @@ class ShardedGraph:
             return finish
         # halo: only rows with entries travel; absent rows are exact zeros in the other forms
         pack = self._rows_gather(partial, ch.touch_rows)
-        recv, work = self._all_to_all_v(pack, ch.recv_counts, ch.touch_counts, direct)
+        recv, work = self._all_to_all_v(pack, ch.recv_counts, ch.touch_counts, direct, role=("rs", K, ch.k))
 
         def finish(y_hub):
             work.wait()
@@ -915,29 +957,37 @@ class ShardedGraph:
         if rp > 0:
             d.B_reg = self.engine.make_op(row[cut:] - hp, col[cut:], val[cut:], rp, W * hp + rp)
 
-    def spmm_adam_w1(self, g_local: Tensor, adam) -> None:
+    def spmm_adam_w1(self, g_local: Tensor, adam, hub_block: Optional[Tensor] = None, pending=None) -> None:
         """W1_local <- Adam(W1_local, M^T @ g) with the regular rows' update INSIDE the SpMM that computes their gradient
         (`GraphPlan.spmm_adam`, split operand: gathered hub block | own rows) -- the [rp, F] gradient and the optimizer's
         pass over those rows disappear, as `optim.Adam.fuse_into_backward` does on one device.  The hub slice takes the
         plain road: its gradient rows are complete only after the reduce-scatter, then one Adam pass over hp rows.
         `adam(rows, grad_or_None, op, g1, g2)` is the optimizer's closure (pytextgcn_amd.optim.Adam._fused_update_sharded).
-        The exchange is the one of `spmm(..., transpose=True)`: same collectives, same order on every rank."""
+        The exchange is the one of `spmm(..., transpose=True)`: same collectives, same order on every rank.
+        `hub_block` [W * hp, F]: the operand's hub rows of EVERY rank, already present here (the narrow exchange forms
+        them locally, pytextgcn_amd/narrow.py) -- nothing is gathered, `g_local` is then this rank's REGULAR rows [rp, F]
+        only, and `pending` the reduce closures of A_r's partial sums if the caller started them already."""
         d = self.dirs[1 if not self.symmetric else 0]
         hp, rp = self.hp, self.rp
-        if g_local.shape[0] != self.n_local:
-            raise ValueError(f"operand has {g_local.shape[0]} rows, this rank owns {self.n_local}")
         if g_local.size(1) <= self._NARROW:
             raise ValueError("spmm_adam_w1 serves the wide (hidden) width only")
         self._split_B(d)
         g_local = g_local.contiguous()
-        xbuf, gathered = self._start_gather(d, g_local)
-        pending = []
-        if d.A is not None:
-            xr = g_local[hp:]
-            for ch in d.chunks[self.rs_chunks]:
-                pending.append(self._start_reduce(ch, ch.op.spmm(xr)))
+        if hub_block is None:
+            if g_local.shape[0] != self.n_local:
+                raise ValueError(f"operand has {g_local.shape[0]} rows, this rank owns {self.n_local}")
+            xbuf, gathered = self._start_gather(d, g_local)
+            own = g_local[hp:] if rp > 0 else None
+        else:
+            if g_local.shape[0] != rp or hub_block.shape != (self.world * hp, g_local.size(1)):
+                raise ValueError("with `hub_block` [W * hp, F] the operand is the rank's regular rows [rp, F]")
+            xbuf, gathered, own = hub_block, (lambda: None), (g_local if rp > 0 else None)
+        if pending is None:
+            pending = []
+            if d.A is not None:
+                for ch in d.chunks[self.rs_chunks]:
+                    pending.append(self._start_reduce(ch, ch.op.spmm(own)))
         gathered()
-        own = g_local[hp:] if rp > 0 else None
         y_hub = d.B_hub.spmm(xbuf, None, x2=own) if d.B_hub is not None else None
         if d.B_reg is not None:
             adam(slice(hp, hp + rp), None, d.B_reg, xbuf, own)        # overlaps the reduce-scatter
@@ -1074,10 +1124,25 @@ class ShardedGCN(nn.Module):
     over ranks after backward (W1's gradient rows are owned and need no reduction)."""
 
     def __init__(self, sg: ShardedGraph, in_channels, out_channels, n_gcn=2, n_hidden_gcn=64,
-                 activation=nn.ReLU, dropout=0.5):
+                 activation=nn.ReLU, dropout=0.5, narrow_exchange: bool = False, keyed_dropout: Optional[bool] = None):
+        """`narrow_exchange` (opt-in; two layers, a hub partition, widths that are multiples of 4): hub rows cross the
+        links at the class width wherever the activation-free network allows it -- pytextgcn_amd/narrow.py; fp32-equal to
+        the plain exchange (1e-5), not bit-equal.  `keyed_dropout`: the fused dropout's mask is a function of a node's
+        position in the PARTITION and of a seed common to the group (so any rank can evaluate a hub row's mask) instead of
+        the local row and a per-rank seed; implied by `narrow_exchange`, available on its own so that the two exchanges
+        can be run on identical masks."""
         super().__init__()
         if in_channels != sg.num_nodes:
             raise ValueError("ShardedGCN implements the one-hot feature case: in_channels must equal num_nodes")
+        self.narrow_exchange = bool(narrow_exchange)
+        self.keyed_dropout = self.narrow_exchange if keyed_dropout is None else bool(keyed_dropout)
+        if self.narrow_exchange:
+            if n_gcn != 2 or sg.rp == 0 or out_channels % 4 or n_hidden_gcn % 4:
+                raise ValueError("narrow_exchange serves the two-layer network over a hub partition (hubs given, regular "
+                                 "rows on every rank) with hidden and class widths that are multiples of 4")
+            if not self.keyed_dropout:
+                raise ValueError("narrow_exchange needs keyed_dropout (every rank evaluates the hub rows' mask)")
+        self._seed_base, self._seed_calls = None, 0
         self.sg = sg
         self.activation = activation()
         self.dropout = dropout
@@ -1104,12 +1169,37 @@ class ShardedGCN(nn.Module):
             sd[f"layers.{i}.bias"] = b.detach().clone()
         return sd
 
+    def _common_seed(self) -> Tensor:
+        """The dropout seed of this forward pass, the SAME on every rank of the group (keyed dropout): a base drawn by
+        the group's first rank and broadcast once (collective: every rank reaches its first training forward together),
+        advanced by a counter that moves in lock step.  A device int64[1], written without a synchronisation."""
+        dev = self.weights[0].device
+        if self._seed_base is None:
+            t = torch.empty(1, dtype=torch.int64, device=dev if dist.get_backend(self.sg.group) == "nccl" else "cpu").random_()
+            dist.broadcast(t, src=dist.get_global_rank(self.sg.group, 0), group=self.sg.group)
+            self._seed_base = int(t.item())
+        self._seed_calls += 1
+        return torch.full((1,), _wrap64(self._seed_base + self._seed_calls * 0x9E3779B97F4A7C15), dtype=torch.int64, device=dev)
+
     def forward(self, g=None) -> Tensor:
         """Logits of this rank's rows, [n_local, out_channels] (padding rows hold the bias)."""
-        x = self._layer1()
         eng = self.sg.engine
+        fused_drop = self.training and 0.0 < self.dropout < 1.0
+        if self.narrow_exchange:
+            from . import conv
+            from .narrow import NarrowGCN2
+            seed = self._common_seed() if fused_drop else None
+            if self.training and self.dropout >= 1.0:
+                raise ValueError("narrow_exchange: dropout must be < 1")
+            cache = self.__dict__.setdefault("_narrow_cache", {}) if conv._REUSE else None
+            return NarrowGCN2.apply(self.sg, self.weights[0], self.biases[0], self.weights[1], self.biases[1],
+                                    float(self.dropout) if fused_drop else 0.0, seed, cache)
+        x = self._layer1()
         for i in range(1, len(self.weights)):
-            if self.training and 0.0 < self.dropout < 1.0 and hasattr(eng, "xw_dropout"):
+            if fused_drop and self.keyed_dropout and hasattr(eng, "xw_dropout_keyed"):
+                from .narrow import own_row_keys
+                xw = eng.xw_dropout_keyed(x, self.weights[i], float(self.dropout), self._common_seed(), own_row_keys(self.sg))
+            elif fused_drop and hasattr(eng, "xw_dropout"):
                 xw = eng.xw_dropout(x, self.weights[i], float(self.dropout))
             else:
                 x = nn.functional.dropout(x, p=self.dropout, training=self.training)

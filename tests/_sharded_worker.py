@@ -57,6 +57,24 @@ class OracleEngine:
     def xw(self, x, w):
         return torch.matmul(x, w)                 # test-only engine: the dense layers of the CPU rehearsal
 
+    # the three layer-2 products of the narrow exchange (pytextgcn_amd/narrow.py), without dropout: the fused mask is a
+    # device hash this CPU engine does not have
+    def gemm_nn(self, a, b, p=0.0, seed=None, record_mask=False, keys=None, out=None):
+        assert seed is None and not record_mask
+        c = torch.matmul(a, b)
+        if out is not None:
+            out.copy_(c)
+            c = out
+        return c
+
+    def gemm_nt(self, a, b, p=0.0, seed=None, mask=None, keys=None):
+        assert seed is None and mask is None
+        return torch.matmul(a, b.t())
+
+    def gemm_tn(self, a, g, p=0.0, seed=None, mask=None, keys=None):
+        assert seed is None and mask is None
+        return torch.matmul(a.t(), g)
+
 
 def rel_err(a, b):
     return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
@@ -142,6 +160,8 @@ def check(kind, device="cpu"):
 
     check_exchange_forms(sg, x, b)
     check_offline_construction(sg, g, hubs, N)
+    if sg.rp > 0:
+        check_narrow_exchange(sg, g, N)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
     torch.manual_seed(3)
@@ -216,6 +236,83 @@ def check(kind, device="cpu"):
     finally:
         pkg.enable_activation_reuse(False)
         sg.spmm = real_spmm
+
+
+def check_narrow_exchange(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, steps=3, fuse_w1=False):
+    """ShardedGCN(narrow_exchange=True) against the plain exchange on the same partition, weights and (with dropout) the
+    SAME keyed mask: losses, logits and every gradient over `steps` Adam(amsgrad) steps at 1e-5 (the sums associate
+    differently over ranks: not bits); the narrow form's collectives are counted."""
+    import pytextgcn_amd as pkg
+    from pytextgcn_amd.narrow import exchange_floats_per_hub_row
+    dev = dev if dev is not None else torch.device("cpu")
+    torch.manual_seed(21)
+    init = O.GCNOracle(N, classes, n_hidden_gcn=hidden, dropout=0.0).state_dict()
+    y_l, m_l = sg.scatter_rows(g.y.to(dev) % classes), sg.scatter_rows(g.train_mask.to(dev))
+    calls = {"all_reduce": 0, "all_gather_into_tensor": 0, "reduce_scatter_tensor": 0}
+    real = {k: getattr(dist, k) for k in calls}
+
+    def counted(name):
+        def f(*a, **kw):
+            calls[name] += 1
+            return real[name](*a, **kw)
+        return f
+    models, opts, traces = [], [], []
+    for narrow in (False, True):
+        m = sharded.ShardedGCN(sg, N, classes, n_hidden_gcn=hidden, dropout=dropout, narrow_exchange=narrow,
+                               keyed_dropout=True).to(dev)
+        m.load_full_state_dict(init)
+        m._seed_base = 1234567                                # the same masks in both models (no broadcast needed)
+        if dev.type == "cpu":
+            o = torch.optim.Adam(m.parameters(), lr=0.02, amsgrad=True)
+        else:
+            o = pkg.optim.Adam(m.parameters(), lr=0.02, amsgrad=True)
+            if fuse_w1:
+                o.fuse_into_backward(m.weights[0])
+        models.append(m), opts.append(o)
+    for step in range(steps):
+        outs = []
+        for m, o, narrow in zip(models, opts, (False, True)):
+            m.train()
+            if narrow and step == 0 and sg.exchange == "collective":
+                for k in calls:
+                    setattr(dist, k, counted(k))
+            try:
+                lo = m()
+                loss = sharded.sharded_cross_entropy(sg, lo, y_l, m_l)
+                o.zero_grad(set_to_none=True)
+                loss.backward()
+            finally:
+                for k in calls:
+                    setattr(dist, k, real[k])
+            if narrow and step == 0 and sg.exchange == "collective":
+                # forward AG(h) AR(C) RS(C) | backward AG(C) AR(C) RS(h): two all-gathers, two all-reduces, two reduce-scatters
+                assert calls == {"all_reduce": 2, "all_gather_into_tensor": 2, "reduce_scatter_tensor": 2 * sg.rs_chunks}, calls
+            m.sync_grads()         # (a rank's share of dW2 differs between the two forms; the sums over ranks agree)
+            grads = [None if p.grad is None else p.grad.detach().clone() for p in m.parameters()]
+            outs.append((loss.detach().clone(), lo.detach().clone(), grads))
+            o.step()
+        (l0, z0, g0), (l1, z1, g1) = outs
+        assert abs(l0.item() - l1.item()) <= 1e-5 * abs(l0.item()) + 1e-9, (step, l0, l1)
+        assert rel_err(z1.cpu(), z0.cpu()) < 1e-5, (step, rel_err(z1.cpu(), z0.cpu()))
+        for a, b in zip(g0, g1):
+            assert (a is None) == (b is None)
+            if a is not None and a.numel() and float(a.abs().max()) > 0:
+                assert rel_err(b.cpu(), a.cpu()) < 1e-5, (step, tuple(a.shape), rel_err(b.cpu(), a.cpu()))
+    # The parameters after `steps` Adam steps: Adam divides a gradient by its own magnitude, so an element whose gradient
+    # is zero to rounding can move by +-lr in one form and -+lr in the other (the two forms add a hub row's partial sums in
+    # different orders).  What must hold: all but a vanishing share of the elements agree to 1e-5 of the largest, and no
+    # element differs by more than the optimizer could have moved it.
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        pa, pb = pa.detach().double().cpu(), pb.detach().double().cpu()
+        diff, scale = (pb - pa).abs(), float(pa.abs().max())
+        off = float((diff > 1e-5 * scale).double().mean())
+        assert off < 2e-3 and float(diff.max()) <= 2.0 * 0.02 * steps * 1.001, (tuple(pa.shape), off, float(diff.max()))
+    # eval forward (no dropout): the narrow form against the plain one
+    for m in models:
+        m.eval()
+    with torch.no_grad():
+        assert rel_err(models[1]().cpu(), models[0]().cpu()) < (1e-5 if dropout == 0.0 else 1e-4)   # (on diverged weights)
+    assert exchange_floats_per_hub_row(200, 64, True) == 784 and exchange_floats_per_hub_row(200, 64, False) == 1056
 
 
 def check_offline_construction(sg, g, hubs, N, engine=None):
@@ -319,6 +416,11 @@ def check_hip(kind, g, hubs, N, dev):
         assert rel_err(got.cpu(), ref) < 1e-5, (kind, transpose, rel_err(got.cpu(), ref))
     check_offline_construction(sga, gd, hubs_d, N, engine=sharded.HipEngine())
     del sga
+    if sg.rp > 0:
+        # the narrow exchange against the plain one on the SAME keyed dropout mask (p = 0.5), plain and with W1's Adam
+        # update inside the backward SpMM
+        check_narrow_exchange(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8)
+        check_narrow_exchange(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, fuse_w1=True)
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
@@ -372,7 +474,7 @@ def check_fused_w1(sg, gd, N, dev, F=200):
         return model, opt, torch.stack(losses)
     plain, _, l_plain = run(False)
     fused, opt_f, l_fused = run(True)
-    assert sg.dirs[0].B_reg is not None or sg.rp == 0
+    assert sg.dirs[0 if sg.symmetric else 1].B_reg is not None or sg.rp == 0
     assert torch.allclose(l_fused, l_plain, rtol=1e-5, atol=1e-8), (l_fused, l_plain)
     for a, b in zip(fused.parameters(), plain.parameters()):
         assert rel_err(a.detach().cpu(), b.detach().cpu()) < 2e-5, rel_err(a.detach().cpu(), b.detach().cpu())
