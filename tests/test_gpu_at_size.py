@@ -31,7 +31,7 @@ def test_config_c4_reference_order_mode_reproduces_the_oracles_weights_and_meets
     last; (dis[src] * w) * dis[dst]) -- what textgcn/lib/models.py:11-20 executes.  All 52 M weights of the c4 plan
     equal the oracle's bit for bit, M^T is stored (PyG's association is not symmetric), and the eval forward of
     GCN(N -> 200 -> 64) over all 2 M rows is within 1e-5 of the fp32 oracle's network (the accurate mode is 1.3e-5 from
-    it because the oracle's hub degrees are)."""
+    it because the oracle's hub degrees are, HISTORY.md 2.2)."""
     N, F, C = c4case.N, 200, 64
     g = c4case.g
     plan = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum="reference")

@@ -37,7 +37,7 @@ def row_rel_err(a, b):
 
 
 def _report(key, **values):
-    """Numbers a reader of DESIGN.md section 2.2 wants to see (who is how far from the float64 truth): appended to
+    """Numbers a reader of HISTORY.md section 2.2 wants to see (who is how far from the float64 truth): appended to
     gpurun_out/parity_report.jsonl when that directory exists.  Never part of an assertion."""
     import json
     import os
@@ -681,11 +681,11 @@ def test_config_c4_full_size_properties_and_sampled_rows(cuda):
 
 def _assert_csr_equal(rp, col, val, rp_ref, col_ref, val_ref, truth=None, case=None):
     """Index arrays bit-exact; weights within 2e-6 of the largest one (the 1-ulp association difference of
-    DESIGN.md section 1 plus the oracle's sequential fp32 degree sums) and, entry by entry, within 5e-5 relative
+    HISTORY.md section 1 plus the oracle's sequential fp32 degree sums) and, entry by entry, within 5e-5 relative
     of the fp32 ORACLE.  That per-entry slack is the oracle's, not the plan's: with `truth` (the float64 weights in
     the same order) the plan must be within 2e-6 of the truth entry by entry, and the oracle's own distance from it
     -- ~2.6e-5 on the rows of the heaviest word nodes, whose degree the reference formulation sums sequentially
-    in fp32 over ~10^6 terms -- is measured and reported."""
+    in fp32 over ~10^6 terms -- is measured and reported (HISTORY.md section 2.2)."""
     assert torch.equal(rp.cpu().long(), rp_ref)
     assert torch.equal(col.cpu(), col_ref)
     v, vr = val.cpu().double(), val_ref.double()
@@ -1974,7 +1974,7 @@ def test_non_finite_operand_rows_with_and_without_the_hot_block(cuda, monkeypatc
     so a plan built with TGCN_HOT_ROWS=0 matches the oracle row for row, non-finite entries included.  The
     dense hot block (default on word-document shapes) multiplies EVERY operand row by a possibly-zero
     weight, so there 0 * inf = nan also lands in hot rows WITHOUT an edge to the column: the documented
-    deviation (include/tgcn.h), confined to the hot rows and to the poisoned feature column."""
+    deviation (include/tgcn.h, HISTORY.md 4.2b), confined to the hot rows and to the poisoned feature column."""
     n, n_hubs = 6000, 12
     gen = torch.Generator().manual_seed(77)
     ei, w = _hub_graph(n, n_hubs, gen)

@@ -172,7 +172,7 @@ def test_fused_dropout_hash_has_no_measurable_structure():
     """The keep decision of the fused dropout is a stateless hash of (seed, row, col) (csrc/dense.hip: drop_row_key,
     drop_col_term, drop_elem), restated here in numpy: keep rate, per-column rates and the correlation between
     adjacent columns, columns two apart and adjacent rows stay within 4 sigma over 4 M elements, for three seeds and
-    three rates.  (A one-multiply finaliser fails this at columns two apart, z = +5 ... +6: DESIGN.md 4.5.)  The
+    three rates.  (A one-multiply finaliser fails this at columns two apart, z = +5 ... +6: HISTORY.md 4.5.)  The
     GPU side reads the real mask back in test_fused_dropout_gemms_share_one_mask."""
     import numpy as np
     m32 = np.uint64(0xFFFFFFFF)

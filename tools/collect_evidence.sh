@@ -9,8 +9,8 @@ QUICK=${2:-}
 mkdir -p $R
 root="$PWD"
 export TMPDIR=/tmp
-BENCH="$root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity"
-echo "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity" > $R/command.txt
+BENCH="$root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity --mode reference"
+echo "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-epoch --no-hbm-activity --mode reference" > $R/command.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$R/stats -- python3 $BENCH > $root/$R/stats.log 2>&1 || { tail -5 $root/$R/stats.log; exit 1; }
 echo "stats done"

@@ -8,8 +8,8 @@ R=gpurun_out/$tag
 mkdir -p $R
 root="$PWD"
 export TMPDIR=/tmp
-BENCH="$root/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-epoch --no-hbm-activity"
-echo "python3 bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-epoch --no-hbm-activity" > $R/command.txt
+BENCH="$root/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-epoch --no-hbm-activity --mode reference"
+echo "python3 bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-epoch --no-hbm-activity --mode reference" > $R/command.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$R/stats -- python3 $BENCH > $root/$R/stats.log 2>&1 || { tail -5 $root/$R/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/$R/fetch -- python3 $BENCH > $root/$R/fetch.log 2>&1 || exit 1

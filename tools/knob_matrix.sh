@@ -1,5 +1,5 @@
 #!/bin/bash
-# The single-process GPU parity tests under the settings of the knobs the library still reads.
+# The single-process GPU parity tests under the settings of the knobs the library still reads (HISTORY.md 4.8).
 set -u
 R=gpurun_out/knobs
 mkdir -p $R

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json[c4_n<W>] from the passes of tools/collect_local_step_traffic.sh: bytes the local operators of rank 0 of a
+"""profiles/traffic.json[<cfg>_n<W>] from the passes of tools/collect_local_step_traffic.sh: bytes the local operators of rank 0 of a
 W-rank partition move over the L2 <-> fabric link per distributed SpMM = sum over ALL dispatches of the step's kernels of
 (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 / steps (same correction as the single-device entries: MI355X_MICROARCH.md 'HBM'), with
 the kernels' summed duration per step from the trace pass.  The exchange's own bytes (RCCL) are not in it.
-  python tools/local_step_traffic.py gpurun_out/<tag>"""
+  python tools/local_step_traffic.py gpurun_out/<tag> [c4|c5]"""
 import csv
 import glob
 import json
@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 src = sys.argv[1]
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c4"
 db_path = os.path.join(ROOT, "profiles", "traffic.json")
 db = json.load(open(db_path))
 
@@ -57,7 +58,7 @@ for W in (2, 4, 8):
         totals[ctr] = t / steps
     total = (2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]) * 1024.0
     kernel_ms = sum(dur.values()) / steps / 1e3
-    db[f"c4_n{W}"] = {
+    db[f"{cfg}_n{W}"] = {
         "bytes_per_launch": total,
         "what": f"the LOCAL operators of rank {rank} of the {W}-rank partition (hot block, gather and second pass of A_r, gather and "
                 "second pass of B_r, the add of the reduce-scattered rows), measured on ONE GPU with tools/prof_local_step.py: "
@@ -70,6 +71,6 @@ for W in (2, 4, 8):
         "launch_ms_rocprof_kernel_sum": kernel_ms, "launch_ms_hip_events": ms_events,
         "fabric_GBps_at_rocprof_launch_time": total / (kernel_ms * 1e-3) / 1e9,
         "round": os.path.basename(src.rstrip("/")), "kernel_sha16": bench.spmm_kernel_sha16()}
-    print(f"c4_n{W}: {total / 1e9:.3f} GB per SpMM over the fabric, kernels {kernel_ms:.3f} ms "
-          f"({db[f'c4_n{W}']['fabric_GBps_at_rocprof_launch_time']:.0f} GB/s), HIP events {ms_events:.3f} ms")
+    print(f"{cfg}_n{W}: {total / 1e9:.3f} GB per SpMM over the fabric, kernels {kernel_ms:.3f} ms "
+          f"({db[f'{cfg}_n{W}']['fabric_GBps_at_rocprof_launch_time']:.0f} GB/s), HIP events {ms_events:.3f} ms")
 json.dump(db, open(db_path, "w"), indent=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel trace of rank 0 of a 2-rank RCCL run on ONE GPU: rank 1 runs beside it unprofiled.  No launcher:
+# Kernel trace of rank 0 of a 2-rank RCCL run on ONE GPU (HISTORY 6.7): rank 1 runs beside it unprofiled.  No launcher:
 # rocprofv3 gets `python3 bench.py` itself, the rank's environment is exported here.
 #   bash tools/trace_rccl_overlap.sh <chunks>
 set -u
