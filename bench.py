@@ -607,7 +607,8 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     layers fused into the layer-2 GEMMs (pytextgcn_amd.enable_fused_dropout).
     "Metric transfer" (BASELINE.md section 2): the arg-max of the masked logits is taken on the
     device and the PREDICTIONS go to the host (fused loop: the rows of both masks gathered through row lists
-    taken once, as int32, into pinned memory, with the two loss values: one synchronisation per epoch); the reference ships the masked logits themselves
+    taken once, as the narrowest integer type that holds a class id, into pinned memory, with the two loss values: one
+    synchronisation per epoch); the reference ships the masked logits themselves
     (flat_amazon.py:111-112) and runs numpy / sklearn on them, which is host work outside this path."""
     import pytextgcn_amd as pkg
     from pytextgcn_amd.functional import masked_cross_entropy
@@ -651,9 +652,12 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
                     # selection inside the epoch is a gather (boolean indexing synchronises to size its result)
                     n_val = int(g.val_mask.sum().item())
                     rows_sel = torch.cat([g.val_mask.nonzero().flatten(), g.train_mask.nonzero().flatten()])
-                    host = (n_val, rows_sel, torch.empty(rows_sel.numel(), dtype=torch.int32).pin_memory(),
+                    # a class id crosses PCIe in the narrowest integer that holds it (64 classes: one byte per row --
+                    # 1.6 MB instead of 6.5 MB at c4, ~0.09 ms of the epoch's tail; numpy / sklearn take any integer labels)
+                    pred_dtype = torch.uint8 if n_classes <= 256 else torch.int16 if n_classes <= 32767 else torch.int32
+                    host = (n_val, rows_sel, torch.empty(rows_sel.numel(), dtype=pred_dtype).pin_memory(),
                             torch.empty(2, dtype=torch.float32).pin_memory())
-                host[2].copy_(pred.index_select(0, host[1]).int(), non_blocking=True)
+                host[2].copy_(pred.index_select(0, host[1]).to(host[2].dtype), non_blocking=True)
                 host[3].copy_(torch.stack([loss.detach(), val_loss]), non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 pred_val, pred_train = host[2][:host[0]].numpy(), host[2][host[0]:].numpy()

@@ -36,11 +36,11 @@ def _stale() -> bool:
 
 
 # Kernels that feed their operand through an INLINE-ASM load ring with hand-counted s_waitcnt (dense.hip: the fully
-# unrolled k_gemm_tall<.., NQ > 0, ..> and k_gemm_tall_split): the compiler's wait-count pass does not know those
+# unrolled k_gemm_tall<.., NQ > 0, ..>, k_gemm_tall_split and the block-pipelined k_gemm_pipe): the compiler's wait-count pass does not know those
 # registers are pending, so a spill or a scratch copy of a ring register between issue and wait would read stale data
 # without any diagnostic.  The build therefore FAILS when one of them uses scratch memory or spills vector registers
 # (hipcc -Rpass-analysis=kernel-resource-usage).
-_RING_KERNEL = re.compile(r"(k_gemm_tall_split|11k_gemm_tallILi\d+ELb[01]ELb[01]ELi[1-9]\d*E)")
+_RING_KERNEL = re.compile(r"(k_gemm_tall_split|k_gemm_pipe|11k_gemm_tallILi\d+ELb[01]ELb[01]ELi[1-9]\d*E)")
 
 
 def check_asm_ring_kernels(remarks: str) -> None:

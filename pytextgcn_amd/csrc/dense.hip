@@ -70,8 +70,18 @@ struct Drop {
     int64_t key_split, key0, key1;
 };
 
+#ifndef TGCN_NT_PIPE
+#define TGCN_NT_PIPE 1                // 0: A/B builds with the class-width nt product on k_gemm_tall (tools/build_variant.py)
+#endif
+#ifndef TGCN_DROP_ROW_KEYS
+#define TGCN_DROP_ROW_KEYS 1          // 0: A/B builds without the row-key mapping (tools/build_variant.py)
+#endif
 __device__ __forceinline__ int64_t drop_row_of(const Drop &d, int64_t row) {
+#if TGCN_DROP_ROW_KEYS
     return row + (row < d.key_split ? d.key0 : d.key1);
+#else
+    return row;
+#endif
 }
 
 // The recorded keep mask of a [N x k] operand: 4 bits per (row, 8-column step q, lane half h) -- the 4 consecutive
@@ -430,6 +440,193 @@ __global__ __launch_bounds__(256, (TRANS_B && NT <= 7 && NQ != 28 && (DROP || CO
     if constexpr (COLSUM) {
         // a lane's rows in block order, then the two halves of the wave, then the four waves
         float *cl = lds + ((k + 7) & ~7) * npad;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float v = csum[t] + __shfl_xor(csum[t], 32, 64);
+            if (half == 0) cl[wave * npad + 32 * t + r] = v;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x)
+            colpart[int64_t(blockIdx.x) * n + j] = (cl[j] + cl[npad + j]) + (cl[2 * npad + j] + cl[3 * npad + j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The input-gradient product of the class-width layer, C[N, n] = A[N, 64] @ B[n, 64]^T (n <= 32 NT), with the operand of
+// block b + 1 in flight under the MFMAs of block b (round 5).
+//
+// k = 64 is ONE ring of eight 16-byte pieces per lane, so k_gemm_tall<.., NQ = 8, ..> issues all of a block's loads at the top
+// of the block and its first MFMA waits out a whole memory latency -- with one wave per SIMD (the placement the unmasked
+// kernels prefer) nothing covers it: ~6 k of the ~22 k cycles a block takes.  Here a wave owns TWO rings and its loop body
+// two blocks: ring B is issued before block b0's k-loop and waited for (free: 14 k cycles later) before b0's epilogue, ring
+// A for the block after next is issued before block b1's k-loop and waited for before b1's epilogue.  Every inline-asm
+// load is therefore complete at the loop's back edge -- hipcc may copy loop-carried asm outputs there, which must not happen
+// to a register whose load is still in flight (HISTORY 4.5) -- and the only exposed latency is the prologue's.  The waits
+// sit BEFORE the epilogues because loads and stores share one counter (vmcnt) on this part: behind 112 stores no counted
+// wait could single out the loads.  B fragments are fetched one s4-step ahead (2 x NT registers instead of 2 x 4 x NT), which
+// pays for the second ring; accumulators, rings and fragments stay in one 256-register file (__launch_bounds__(256, 2):
+// 224-250 registers, no spills -- the build checks).
+// Epilogues: plain, COLSUM (column sums of the stored rows), and DROP with the mask read from the forward product's record
+// (BITS; Drop::bits) -- bit for bit k_gemm_tall's results: same products, same summation orders.
+// Measured at c4 (tools/ab_dense.py, profiles/r05_ab_dense.log): nt 0.585 -> 0.52 ms, nt + column sums 0.58 -> 0.535, nt +
+// mask from the record + column sums 0.665 -> 0.59.  The same scheme for the hidden-width nn product (two rings of 25 pieces
+// = 200 registers, plain loads so that the compiler may use the second half of the register file) was built and measured
+// SLOWER (nn 0.525 -> 0.61 ms: 96 accumulator-file registers of copies) and removed.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NQ, bool TRANS_B, bool COLSUM, bool BITS>
+__global__ __launch_bounds__(256, 2) void k_gemm_pipe(const float *__restrict__ A, int64_t lda,
+                                                        const float *__restrict__ B, int64_t ldb,
+                                                        float *__restrict__ C, int64_t ldc, int64_t N, int n,
+                                                        const Drop drop, float *__restrict__ colpart) {
+    extern __shared__ float lds[];          // [8 NQ][npad] (+ [4][npad] with COLSUM) (+ 4 x 256 mask words with BITS)
+    constexpr int npad = 32 * NT, K = 8 * NQ;
+    float csum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) csum[t] = 0.f;
+    for (int idx = threadIdx.x; idx < K * npad; idx += blockDim.x) {
+        const int kk = idx / npad, j = idx % npad;
+        lds[idx] = j < n ? (TRANS_B ? B[int64_t(j) * ldb + kk] : B[int64_t(kk) * ldb + j]) : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int64_t n_blocks = (N + 31) / 32;
+    const int64_t stride = int64_t(gridDim.x) * 4;
+    const float *bbase = lds + (4 * half) * npad + r;
+    uint32_t *mw = nullptr;
+    if constexpr (BITS) mw = reinterpret_cast<uint32_t *>(lds + K * npad + (COLSUM ? 4 * npad : 0)) + wave * 256;
+
+    // rows past the end shadow the last row: loads stay in bounds, their results are not stored
+    auto arow_of = [&](int64_t blk) __attribute__((always_inline)) { return A + std::min(std::min(blk, n_blocks - 1) * 32 + r, N - 1) * lda + 4 * half; };
+#define TGCN_ISSUE(ring, ptr)                                                                                         \
+    do {                                                                                                              \
+        const float *p_ = (ptr);                                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_)                                                             \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[j_]) : "v"(p_ + 8 * j_) : "memory");           \
+    } while (0)
+    // the wait takes every slot of the ring as an in/out operand, so that no consumer can be scheduled above it
+#define TGCN_R8(ring, o) "+v"(ring[o]), "+v"(ring[o + 1]), "+v"(ring[o + 2]), "+v"(ring[o + 3]), "+v"(ring[o + 4]), \
+                         "+v"(ring[o + 5]), "+v"(ring[o + 6]), "+v"(ring[o + 7])
+#define TGCN_ARRIVED(ring)                                                                                            \
+    do {                                                                                                              \
+        static_assert(NQ == 8, "a ring is the whole operand row block: eight 16-byte pieces per lane (k = 64)");       \
+        asm volatile("s_waitcnt vmcnt(0)" : TGCN_R8(ring, 0)::"memory");                                              \
+    } while (0)
+    auto mask_of = [&](int64_t blk) __attribute__((always_inline)) {
+        uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (BITS) {
+            const int64_t mrow_ = blk * 32 + (lane >> 1);
+            if (mrow_ < N) mq = *reinterpret_cast<const uint4 *>(drop.bits + mrow_ * drop.bits_stride + 4 * (lane & 1));
+        }
+        return mq;
+    };
+    auto kloop = [&](const f32x4 (&ring)[NQ], f32x16 (&acc)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        float bfr[2][NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bfr[0][t] = bbase[32 * t];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 a = ring[q];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int step = 4 * q + s4;
+                if (step + 1 < 4 * NQ) {                  // the fragments of the next step, under this step's MFMAs
+                    const float *bq = bbase + (8 * ((step + 1) >> 2) + ((step + 1) & 3)) * npad;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bfr[(step + 1) & 1][t] = bq[32 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], bfr[step & 1][t], acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // RAGGED (only the last block of the matrix): rows past N are neither stored nor summed
+    auto store_tiles = [&](auto ragged, int64_t blk, const f32x16 (&acc)[NT], const uint4 mq) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged)::value;
+        const int64_t row0 = blk * 32 + 4 * half;
+        float *crow = C + row0 * ldc + r;
+        if constexpr (BITS) {
+            // column c = 32 t + r of a row is bit 16 (t & 1) + 4 (r / 8) + (r & 3) of word t / 2 of half (r / 4) & 1
+            *reinterpret_cast<uint4 *>(mw + 4 * lane) = mq;
+            __builtin_amdgcn_wave_barrier();
+            const int lane_bit = 4 * (r >> 3) + (r & 3);
+            const uint32_t *mrow = mw + 4 * ((r >> 2) & 1) + 32 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (32 * t + r < n) {
+                    const int bit = lane_bit + 16 * (t & 1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mrow[8 * ro + (t >> 1)]), bit, 1));
+                        const float out = __uint_as_float(__float_as_uint(acc[t][i] * drop.scale) & keep);
+                        if (!RAGGED || row0 + ro < N) {
+                            crow[int64_t(ro) * ldc + 32 * t] = out;
+                            if constexpr (COLSUM) csum[t] += out;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one tile at a time
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (32 * t + r < n) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        const float out = acc[t][i];
+                        if (!RAGGED || row0 + ro < N) {
+                            crow[int64_t(ro) * ldc + 32 * t] = out;
+                            if constexpr (COLSUM) csum[t] += out;
+                        }
+                    }
+                }
+                if constexpr (COLSUM) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto epilogue = [&](int64_t blk, const f32x16 (&acc)[NT], const uint4 mq) __attribute__((always_inline)) {
+        if (blk * 32 + 32 <= N)                            // wave-uniform
+            store_tiles(std::false_type{}, blk, acc, mq);
+        else
+            store_tiles(std::true_type{}, blk, acc, mq);
+    };
+
+    f32x4 ringA[NQ], ringB[NQ];
+    f32x16 acc[NT];
+    int64_t blk = int64_t(blockIdx.x) * 4 + wave;
+    if (blk < n_blocks) {
+        TGCN_ISSUE(ringA, arow_of(blk));
+        TGCN_ARRIVED(ringA);                               // the one exposed latency of this wave
+    }
+    while (blk < n_blocks) {
+        const int64_t blk1 = blk + stride, blk2 = blk1 + stride;
+        TGCN_ISSUE(ringB, arow_of(blk1));                  // (past the end: the last block's rows again, never used)
+        const uint4 mq0 = mask_of(blk);
+        kloop(ringA, acc);
+        TGCN_ARRIVED(ringB);                               // issued a whole k-loop ago: no wait in the steady state
+        epilogue(blk, acc, mq0);
+        if (blk1 >= n_blocks) break;
+        TGCN_ISSUE(ringA, arow_of(blk2));
+        const uint4 mq1 = mask_of(blk1);
+        kloop(ringB, acc);
+        TGCN_ARRIVED(ringA);                               // every asm load is complete at the back edge
+        epilogue(blk1, acc, mq1);
+        blk = blk2;
+    }
+#undef TGCN_ISSUE
+#undef TGCN_ARRIVED
+#undef TGCN_R8
+    if constexpr (COLSUM) {
+        // a lane's rows in block order, then the two halves of the wave, then the four waves (k_gemm_tall's order)
+        float *cl = lds + K * npad;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float v = csum[t] + __shfl_xor(csum[t], 32, 64);
@@ -1287,6 +1484,34 @@ int launch_tall_one(const float *A, int64_t lda, const float *B, int64_t ldb, fl
             }
             return finish();
         }
+#if TGCN_NT_PIPE
+    if (whole && k == 64 && nt == 7 && lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
+        // the block-pipelined kernel (k_gemm_pipe): plain / column sums / mask from the record
+        const bool from_record = DROP && drop.bits && n > 192 && drop.bits_stride % 4 == 0 &&
+                                 reinterpret_cast<uintptr_t>(drop.bits) % 16 == 0;
+        if (!DROP || from_record) {
+            size_t lb = sizeof(float) * (size_t(64) * 224 + (COLSUM ? 4 * 224 : 0)) + (from_record ? 4 * 1024 : 0);
+            // Workgroups per CU, measured at c4 (tools/ab_dense.py, profiles/r05_ab_dense.log): the unmasked kernels want the CU
+            // to themselves (nt 0.515 against 0.565 ms with two, nt + column sums 0.53 / 0.59); the one that masks its result
+            // from the record has ~450 vector-ALU instructions of epilogue per block, which a second workgroup's MFMAs hide
+            // (0.59 against 0.625 ms).  k_gemm_tall, the kernel this replaces: 0.585 / 0.58 / 0.665 ms.
+            const int pipe_per_cu = from_record ? 2 : 1;
+            if (pipe_per_cu == 1) lb = std::max(lb, kOnePerCu);
+            const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({(n_blocks + 3) / 4, int64_t(n_cu) * pipe_per_cu,
+                                                                                      int64_t(kTallMaxGrid)})));
+            grid_used = grid;
+#define TGCN_PIPE(BI)                                                                                              \
+    do {                                                                                                           \
+        const void *fn = reinterpret_cast<const void *>(&k_gemm_pipe<7, 8, true, COLSUM, BI>);                     \
+        TGCN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb))); \
+        k_gemm_pipe<7, 8, true, COLSUM, BI><<<grid, 256, lb, s>>>(A, lda, B, ldb, C, ldc, N, n, drop, colpart);   \
+    } while (0)
+            if (from_record) TGCN_PIPE(true); else TGCN_PIPE(false);
+#undef TGCN_PIPE
+            return finish();
+        }
+    }
+#endif
     if (whole && k == 64 && nt == 7) {
         if constexpr (DROP) {
             // the mask from the forward product's record: n in (192, 256] has four words per row half (16-byte reads)

@@ -363,8 +363,8 @@ def test_committed_round3_bench_line_names_the_basis_of_its_roofline_fraction():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["csr"]["value"] > c["value"] > 0
 
 
-def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
-    """profiles/r04_bench_c4_n1.json (one MI355X, final round-4 library).  The roofline object as frozen in round 4:
+def _check_frozen_roofline_contract(name, exact_committed_traffic):
+    """A committed bench line of the headline configuration (one MI355X).  The roofline object as frozen in round 4:
     `achieved` IS the GB/s `frac` is a fraction of (`frac == achieved / peak`, `achieved == traffic / launch time`), on
     the basis `frac_basis` names -- the counter traffic of profiles/traffic.json, collected on these kernel sources --;
     the algorithmic / fabric / HBM / compulsory figures stand side by side, each consistent with its byte count; nothing
@@ -373,7 +373,7 @@ def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.loads(open(os.path.join(root, "profiles", "r04_bench_c4_n1.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl", "setup_s"):
         assert k in d, k
@@ -395,13 +395,16 @@ def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
     # `traffic` is measured INSIDE the run (two child runs under rocprofv3 --pmc, bench.live_fabric_traffic) when that
     # works, else it is the committed figure; either way the committed figure is in the record, and a live one agrees
     # with it (same kernels, same graph: the counters repeat to a fraction of a per cent)
-    assert r["traffic_fabric_committed"]["bytes_per_launch"] == t["bytes_per_launch"]
+    if exact_committed_traffic:          # the record of the CURRENT round: traffic.json as it stands was on file when it ran
+        assert r["traffic_fabric_committed"]["bytes_per_launch"] == t["bytes_per_launch"]
+    else:                                # an earlier round's record: traffic.json has been re-collected since (same kernels)
+        assert abs(r["traffic_fabric_committed"]["bytes_per_launch"] - t["bytes_per_launch"]) < 1e-3 * t["bytes_per_launch"]
     assert r["traffic_fabric_committed"]["collected_on_these_kernel_sources"] is True
     if r["traffic_fabric_live_note"] and r["traffic_fabric_live_note"].startswith("live:"):
         assert abs(r["traffic"] - t["bytes_per_launch"]) < 0.02 * t["bytes_per_launch"]
         assert r["traffic_basis"].startswith("live:")
     else:
-        assert t["bytes_per_launch"] == r["traffic"]
+        assert abs(t["bytes_per_launch"] - r["traffic"]) < 1e-3 * r["traffic"]
     # the counter run's own launch time (rocprof kernel sum ~ HIP events of the bench inside that run) gives the same rate
     assert abs(t["launch_ms_rocprof_kernel_sum"] - t["launch_ms_bench_hip_events"]) < 0.02 * t["launch_ms_bench_hip_events"]
     assert abs(t["fabric_GBps_at_rocprof_launch_time"] - r["achieved"]) < 0.03 * r["achieved"]
@@ -410,6 +413,26 @@ def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
     assert c["csr"]["value"] > c["value"] > 0
     assert d["rccl"]["ranks"] == 1 and d["rccl"]["distinct_devices"] == 1 and d["rccl"]["devices"][0]["pci_bus_id"]
     assert d["epoch_ms_fused_w1_update_in_backward_with_activation_reuse"] < d["epoch_ms_fused"] < d["epoch_ms"]
+    return d
+
+
+def test_committed_round4_bench_line_holds_the_frozen_roofline_contract():
+    _check_frozen_roofline_contract("r04_bench_c4_n1.json", exact_committed_traffic=False)
+
+
+def test_committed_round5_bench_line_is_in_the_reference_mode_with_the_accurate_mode_beside_it():
+    """profiles/r05_bench_c4_n1.json (final round-5 library): the frozen roofline contract, and what round 5 added -- the
+    headline is the reference-order normalisation mode (the package default: PyG's own fp32 arithmetic, weights bit for
+    bit the oracle's, M^T stored), `config` says so, and the accurate mode's figure of the same run stands beside it and
+    shows that the modes cost the same."""
+    d = _check_frozen_roofline_contract("r05_bench_c4_n1.json", exact_committed_traffic=True)
+    assert d["config"]["normalisation_mode"] == "reference" and "reference" in d["config"]["workload"]
+    assert d["plan"]["mode"] == "reference" and d["plan"]["stores_transpose"] is True
+    acc = d["accurate_mode"]
+    assert acc["mode"] == "accurate" and acc["stores_transpose"] is False and d["value_accurate_mode"] == acc["value"]
+    assert acc["plan_device_bytes"] < 0.6 * d["plan"]["device_bytes"]                  # one stored block instead of two
+    assert abs(d["value"] - acc["value"]) < 0.02 * d["value"]                           # the modes cost the same
+    assert d["rccl"]["hsa_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():

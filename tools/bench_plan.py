@@ -13,14 +13,15 @@ from pytextgcn_amd.plan import GraphPlan  # noqa: E402
 
 for name, N, E in [("c2", 100_000, 2_000_000), ("c4", 2_000_000, 50_000_000)]:
     g = synth.word_doc_graph(N, E, seed=44, device="cuda:0", features="none")
-    GraphPlan(g.edge_index, g.edge_attr, N).close()
-    ts = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        p = GraphPlan(g.edge_index, g.edge_attr, N)
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-        st = p.stats()
-        p.close()
-    print(f"{name}: plan build {min(ts) * 1e3:.1f} ms  {st}")
+    for mode in ("reference", "accurate"):               # the package default first
+        GraphPlan(g.edge_index, g.edge_attr, N, degree_sum=mode).close()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            p = GraphPlan(g.edge_index, g.edge_attr, N, degree_sum=mode)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            st = p.stats()
+            p.close()
+        print(f"{name} [{mode}]: plan build {min(ts) * 1e3:.1f} ms  {st}", flush=True)
