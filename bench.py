@@ -1065,6 +1065,7 @@ def main():
 
     # ---- the headline, complete at this point; everything below is secondary ------------------------------------------
     secondary_errors = {}
+    completed = {}                     # results of the secondary measurements that finished: an aborted record keeps them
     workload = (f"{args.config}: synthetic {'power-law graph' if args.config == 'c5' else 'PMI/TF-IDF word-doc graph'}, N={N}, "
                 f"E={E}, nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G; "
                 + ("normalisation mode 'reference' (PyG-1.6.3 gcn_norm's own fp32 arithmetic, weights bit for bit the "
@@ -1089,19 +1090,30 @@ def main():
         run, and every rank that gets here exits non-zero WITHOUT tearing the group down (its peers may sit in a collective;
         torch.distributed.run ends them when this rank is gone)."""
         print(f"bench.py: rank {rank} aborts in {where}: {err}", file=sys.stderr, flush=True)
-        write_record(dict(headline, aborted={"in": where, "error": err, "rank": rank},
+        write_record(dict(headline, **completed, aborted={"in": where, "error": err, "rank": rank},
                           secondary_errors=dict(secondary_errors, **{where: err})))
         sys.stderr.flush()
         os._exit(1)
     if rank == 0 and world > 1:
-        # a peer that aborts makes torch.distributed.run send SIGTERM to the rest: rank 0 still hands the headline over
+        # A peer that aborts makes torch.distributed.run send SIGTERM to the rest.  Rank 0 is then most likely blocked
+        # inside a collective (C++ code: a Python-level signal handler would only run once the call returns, i.e. at its
+        # timeout, long after the launcher's SIGKILL).  So the signal is routed to a wake-up descriptor and a helper THREAD
+        # -- which runs while the main thread waits inside the collective with the GIL released -- hands the headline over.
         import signal
+        import threading
+        rd, wr = os.pipe()
+        os.set_blocking(wr, False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)       # keep the default action (die at once) from firing
+        signal.set_wakeup_fd(wr, warn_on_full_buffer=False)
 
-        def on_term(signum, frame):
-            write_record(dict(headline, aborted={"in": "SIGTERM (a peer rank ended)", "rank": 0},
-                              secondary_errors=secondary_errors or None))
-            os._exit(1)
-        signal.signal(signal.SIGTERM, on_term)
+        def on_term():
+            while True:
+                b = os.read(rd, 1)
+                if b and b[0] == signal.SIGTERM:
+                    write_record(dict(headline, **completed, aborted={"in": "SIGTERM (a peer rank ended)", "rank": 0},
+                                      secondary_errors=secondary_errors or None))
+                    os._exit(1)
+        threading.Thread(target=on_term, daemon=True, name="bench-sigterm").start()
 
     # what the SpMM pulls from HBM, measured live on this box (outside the timed region; N = 1 only: at N > 1
     # the step contains collectives every rank must enter)
@@ -1120,7 +1132,11 @@ def main():
         import pytextgcn_amd as pkg
         from pytextgcn_amd import dense as _dense
         try:
-            return fn()
+            if os.environ.get("TGCN_BENCH_TEST_FAIL") == "secondary" and world > 1 and rank == world - 1 \
+                    and name == "exchange_diagnostics":
+                raise RuntimeError("test hook: the last rank fails alone inside a guarded section")   # tests/test_zz_gpu_sharded.py
+            completed[name] = fn()
+            return completed[name]
         except Exception as e:                       # noqa: BLE001 - classified here
             err = f"{type(e).__name__}: {e}"[:300]
             print(f"bench.py: {name} failed on rank {rank}: {err}", file=sys.stderr, flush=True)
@@ -1141,6 +1157,8 @@ def main():
 
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
     epoch_ms_narrow = None
+    diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
+        if (world > 1 or force_sharded) else None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
         epoch_ms_fused = secondary("epoch_ms_fused", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist))
@@ -1153,8 +1171,6 @@ def main():
         if sg.rp > 0 and C % 4 == 0 and F % 4 == 0:
             epoch_ms_narrow = secondary("epoch_ms_fused_w1_reuse_narrow_exchange",
                                         lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True))
-    diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
-        if (world > 1 or force_sharded) else None
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = secondary("epoch_ms", lambda: epoch_time_ms(g, F, C, fused=False))

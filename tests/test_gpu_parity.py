@@ -2116,6 +2116,51 @@ def test_fused_dropout_gemms_share_one_mask(cuda, N, h, C, p):
     assert float(dense.gemm_nn(x, w, 1.0, seed).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("h,C,p", [(200, 64, 0.5), (64, 200, 0.5), (100, 20, 0.7), (36, 8, 0.2)])
+def test_dropout_row_keys_place_a_matrix_inside_a_larger_mask(cuda, h, C, p):
+    """tgcn_set_dropout_row_keys(split, key0, key1): row i of the call's matrix takes mask row i + key0 below `split`, i +
+    key1 from there on.  A 600-row matrix keyed onto rows [500, 700) and [2000, 2400) of a 3000-row mask must draw exactly
+    those rows of the unkeyed 3000-row mask in all three dropout products (hashed and from the record), the keys must not
+    leak into the next call (the Python wrappers put the identity back), and negative keys are refused."""
+    from pytextgcn_amd import dense
+    gen = torch.Generator(device=cuda).manual_seed(h * 31 + C)
+    seed = torch.randint(-2**62, 2**62, (1,), device=cuda, generator=gen)
+    big = _drop_mask(3000, h, p, seed, cuda)
+    keys = (200, 500, 2000 - 200)
+    rows = torch.cat([torch.arange(500, 700), torch.arange(2000, 2400)]).to(cuda)
+    want = big[rows]
+    # the mask of the keyed call, read back through the nt product (mask on the result)
+    out = dense.gemm_nt(torch.ones(600, 8, device=cuda), torch.ones(h, 8, device=cuda), p, seed, keys=keys)
+    assert torch.equal(out != 0, want)
+    assert torch.equal(_drop_mask(3000, h, p, seed, cuda), big)                 # the next call is unkeyed again
+    x = torch.randn(600, h, device=cuda, generator=gen)
+    w = torch.randn(h, C, device=cuda, generator=gen)
+    g = torch.randn(600, C, device=cuda, generator=gen)
+    xd = (x * want).double() / (1 - p)
+    ref_nt = (g.double() @ w.double().t()) * want / (1 - p)
+    assert rel_err(dense.gemm_nn(x, w, p, seed, keys=keys), xd @ w.double()) < TOL
+    assert rel_err(dense.gemm_tn(x, g, p, seed, keys=keys), xd.t() @ g.double()) < TOL
+    assert rel_err(dense.gemm_nt(g, w, p, seed, keys=keys), ref_nt) < TOL
+    got = dense.gemm_nt(g, w, p, seed, note_colsums=True, keys=keys)
+    assert rel_err(got, ref_nt) < TOL and rel_err(colsum(got), ref_nt.sum(0)) < 2e-5
+    # ... and through the record: the forward product writes the keyed decisions, the gradient products read them
+    fwd, mask = dense.gemm_nn(x, w, p, seed, record_mask=True, keys=keys)
+    assert rel_err(fwd, xd @ w.double()) < TOL
+    if mask is not None:
+        assert torch.equal(dense.gemm_tn(x, g, p, seed, mask, keys=keys), dense.gemm_tn(x, g, p, seed, keys=keys))
+        assert torch.equal(dense.gemm_nt(g, w, p, seed, note_colsums=True, mask=mask, keys=keys), got)
+    # the autograd wrapper carries the keys into its two gradient products
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    dense.xw_dropout(xr, wr, p, seed, keys=keys).backward(g)
+    assert rel_err(wr.grad, xd.t() @ g.double()) < TOL and rel_err(xr.grad, ref_nt) < TOL
+    # a split of zero keys every row with key1 (a matrix of regular rows handed over on its own)
+    tail = dense.gemm_nt(torch.ones(400, 8, device=cuda), torch.ones(h, 8, device=cuda), p, seed, keys=(0, 0, 2000))
+    assert torch.equal(tail != 0, big[2000:2400])
+    lib = _lib.load()
+    assert lib.tgcn_set_dropout_row_keys(-1, 0, 0) == _lib.E_INVALID
+    assert lib.tgcn_set_dropout_row_keys(0, 0, 0) == _lib.OK
+
+
 @pytest.mark.parametrize("N,h,C,p", [(100_003, 200, 64, 0.5), (4097, 100, 20, 0.7), (333, 36, 8, 0.2), (65, 64, 64, 0.5),
                                      (1, 8, 4, 0.5), (5000, 256, 128, 0.3), (30_001, 200, 219, 0.5), (2_000_003, 200, 64, 0.7)])   # 219: column groups; the last: c4's rows
 def test_recorded_dropout_mask_equals_the_hashed_one(cuda, request, N, h, C, p):

@@ -173,3 +173,35 @@ def test_bench_two_rccl_ranks_sharing_one_gpu_under_torch_distributed_run(cuda):
     rec = _bench_two_rccl_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                  "--master-addr", "127.0.0.1", "--master-port", str(free_port())])
     assert rec["exchange_selection"]["chosen"].startswith("collective")
+
+
+def test_bench_rank_failing_alone_in_a_secondary_measurement_costs_neither_a_hang_nor_the_headline(cuda):
+    """a rank that raises inside a guarded secondary section has left its peers inside a collective.  It must
+    not enter another collective (mis-paired calls) and must not be swallowed: the run ends at once (no 180 s timeout),
+    rank 0 hands over the headline it holds -- marked `aborted`, with the secondaries that had completed -- and, started
+    as a plain command, the launcher's fresh-child fallback delivers a clean record."""
+    import json
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TGCN_BENCH_BACKEND="gloo", TGCN_BENCH_DEVICE="0", TGCN_BENCH_TEST_FAIL="secondary")
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "3", "--warmup", "1"]
+    # (1) under the driver's own launch line: a non-zero exit, quickly, and ONE line that still carries the headline
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(free_port())] + args, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=env, timeout=600, cwd=root)
+    assert res.returncode != 0 and time.time() - t0 < 170, (res.returncode, time.time() - t0)
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, (lines, res.stderr.decode()[-2000:])
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and rec["n_gpus"] == 2 and "aborted" in rec
+    assert rec["distributed_parity"]["ok"] is True            # what had completed before the failure is in the record
+    # (2) as a plain command: the launcher sees the failure and runs the plain configuration in a fresh child
+    res = subprocess.run([sys.executable] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and "exited with code" in rec["fallback"] and "aborted" not in rec
