@@ -30,6 +30,9 @@ p.add_argument("--epochs", type=int, default=30)
 p.add_argument("--backend", default="nccl")
 p.add_argument("--device", type=int, default=None, help="force a device index (several ranks on one GPU: gloo only)")
 p.add_argument("--hidden", type=int, default=100, help="hidden width (flat_amazon.py:26 uses 100)")
+p.add_argument("--narrow", action="store_true",
+               help="ShardedGCN(narrow_exchange=True): hub rows cross the links at the class width where the activation-free "
+                    "network allows (pytextgcn_amd/narrow.py); needs hidden and class widths that are multiples of 4")
 p.add_argument("--fuse-w1", action="store_true",
                help="update this rank's W1 rows inside the backward SpMM (optim.Adam.fuse_into_backward; takes hidden > 128)")
 args = p.parse_args()
@@ -43,7 +46,7 @@ os.environ.setdefault("MASTER_PORT", "29577")
 # RCCL on a high-priority stream: the exchange must be scheduled while the local SpMM grids fill the CUs
 init_process_group(args.backend, dev, rank=rank, world_size=world)
 
-seed, lr, dropout, n_classes = 44, 0.05, 0.5, 6
+seed, lr, dropout, n_classes = 44, 0.05, 0.5, (8 if args.narrow else 6)
 th.manual_seed(seed + rank)                        # dropout streams differ per rank
 if rank == 0:
     docs, y = synth.synthetic_corpus(args.docs, 4000, n_classes=n_classes, seed=seed)
@@ -64,7 +67,7 @@ for t in (coo, attr, labels, masks):
     dist.broadcast(t, 0)
 
 sg = ShardedGraph(coo.t(), attr, N, hubs=th.arange(N, device=dev) < V)
-gcn = ShardedGCN(sg, N, n_classes, n_hidden_gcn=args.hidden, dropout=dropout).to(dev)
+gcn = ShardedGCN(sg, N, n_classes, n_hidden_gcn=args.hidden, dropout=dropout, narrow_exchange=args.narrow).to(dev)
 with th.no_grad():                                  # glorot over the FULL (N, h) matrix
     a = (6.0 / (N + args.hidden)) ** 0.5
     gcn.weights[0].uniform_(-a, a).mul_(sg.real.unsqueeze(1))
