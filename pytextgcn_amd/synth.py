@@ -59,8 +59,18 @@ def _pick(keys: torch.Tensor, n: int, gen: torch.Generator) -> torch.Tensor:
 
 def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_classes: int = 64,
                    vocab_frac: float = 0.1, doc_word_share: float = 0.7, zipf_s: float = 1.07,
-                   features: str = "sparse_identity") -> Data:
-    """PMI / TF-IDF shaped word-document heterograph with exactly `n_edges` directed edges."""
+                   features: str = "sparse_identity", n_topics: int = 0, topic_mass: float = 0.6,
+                   doc_order: str = "by_topic") -> Data:
+    """PMI / TF-IDF shaped word-document heterograph with exactly `n_edges` directed edges.
+
+    `n_topics > 0` gives the corpus TOPICAL LOCALITY, which the plain generator has none of (every document draws from
+    one global Zipf distribution): document d belongs to topic d * n_topics // D, a share `topic_mass` of its words comes
+    from the topic's own slice of the vocabulary (Zipf within the slice), the rest from the global distribution; word-word
+    pairs likewise fall inside one topic's slice with probability `topic_mass`; the label of a document is its topic
+    (mod n_classes).  `doc_order="by_topic"` keeps the documents of a topic adjacent (a corpus file sorted by class, as
+    the reference's DBpedia loader concatenates them, flat_dbpedia.py:41-71), `"shuffled"` re-labels them at random (same
+    graph up to the numbering of the document nodes).  With `n_topics == 0` nothing changes: not one extra random number
+    is drawn, the seed-44 benchmark graphs are bit for bit what they were."""
     if n_edges % 2:
         raise ValueError("n_edges must be even (every edge is emitted in both directions)")
     device = torch.device(device)
@@ -80,6 +90,17 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
         raise ValueError("graph too dense for the requested shape")
     cdf = _zipf_cdf(V, zipf_s, device)
     word_perm = _randperm(V, gen, device)      # vocabulary order is not rank order
+    if n_topics:
+        if doc_order not in ("by_topic", "shuffled") or not 0.0 <= topic_mass <= 1.0 or V // n_topics < 2:
+            raise ValueError("topics: doc_order is 'by_topic' or 'shuffled', 0 <= topic_mass <= 1, >= 2 words per topic")
+        Vt = V // n_topics
+        cdf_t = _zipf_cdf(Vt, zipf_s, device)
+        topic_perm = _randperm(V, gen, device)             # topic t owns topic_perm[t * Vt : (t + 1) * Vt]
+
+        def topical(words, topic):
+            """Replace a share `topic_mass` of the globally drawn words by draws from the topic's own slice."""
+            own = _rand(words.numel(), gen, device) < topic_mass
+            return torch.where(own, topic_perm[topic * Vt + _sample(cdf_t, words.numel(), gen)], words)
 
     # ---- document-word incidences: k_d ~ clip(LogNormal, 4, 400) distinct Zipf words per doc ----
     keys = torch.empty(0, dtype=torch.int64, device=device)
@@ -95,6 +116,8 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
             k = k.clamp_(min(4.0, mean), 400.0).round_().long().clamp_(max=V)
             docs = torch.repeat_interleave(torch.arange(D, device=device), k)
             words = word_perm[_sample(cdf, docs.numel(), gen)]
+            if n_topics:
+                words = topical(words, docs * n_topics // D)
         else:                                  # very dense requests: top up uniformly
             m = 2 * want + 16
             docs = _randint(D, m, gen, device)
@@ -115,6 +138,11 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
         m = 2 * want + 16
         if round_ < 48:
             a, b = word_perm[_sample(cdf, m, gen)], word_perm[_sample(cdf, m, gen)]
+            if n_topics:                       # a pair falls inside ONE topic's slice with probability topic_mass
+                t_pair = _randint(n_topics, m, gen, device)
+                own = _rand(m, gen, device) < topic_mass
+                a = torch.where(own, topic_perm[t_pair * Vt + _sample(cdf_t, m, gen)], a)
+                b = torch.where(own, topic_perm[t_pair * Vt + _sample(cdf_t, m, gen)], b)
         else:
             a = _randint(V, m, gen, device)
             b = _randint(V, m, gen, device)
@@ -146,7 +174,17 @@ def word_doc_graph(n_nodes: int, n_edges: int, seed: int = 44, device="cpu", n_c
     # ---- labels, masks, features ---------------------------------------------------------------
     N = n_nodes
     y = torch.zeros(N, dtype=torch.int64, device=device)
-    y[V:] = _randint(n_classes, D, gen, device)
+    if n_topics:
+        y[V:] = (torch.arange(D, device=device) * n_topics // D) % max(n_classes, 1)
+        if doc_order == "shuffled":            # the same graph with the document nodes re-labelled at random
+            relabel = _randperm(D, gen, device)
+            is_doc0, is_doc1 = coo[:, 0] >= V, coo[:, 1] >= V
+            coo[:, 0] = torch.where(is_doc0, relabel[(coo[:, 0] - V).clamp_(min=0)] + V, coo[:, 0])
+            coo[:, 1] = torch.where(is_doc1, relabel[(coo[:, 1] - V).clamp_(min=0)] + V, coo[:, 1])
+            y_docs = y[V:].clone()
+            y[V + relabel] = y_docs
+    else:
+        y[V:] = _randint(n_classes, D, gen, device)
     order = _randperm(D, gen, device) + V
     n_test, n_val = D // 10, D // 10
     masks = [torch.zeros(N, dtype=torch.bool, device=device) for _ in range(3)]

@@ -455,3 +455,44 @@ def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():
     import gc
     gc.collect()
     assert all(r[0]() is not None for r in plan._PADDED.values())   # dead buffers leave the registry
+
+
+def test_topical_generator_leaves_the_benchmark_graphs_alone_and_has_the_locality_it_claims():
+    """synth.word_doc_graph(..., n_topics=T): the corpus with topical locality of tools/exp_topical_order.py.  With
+    n_topics = 0 (every BASELINE configuration) not one extra random number is drawn -- the seed-44 graphs keep the bytes
+    they had in round 4 (fingerprint of a small instance) --; with topics the same graph comes out in both document orders
+    (edge multiset up to the re-labelling, labels following their documents), documents of a topic are adjacent in the
+    by_topic order and adjacent documents share several times more words than in the shuffled one."""
+    import hashlib
+    from pytextgcn_amd import synth
+    g = synth.word_doc_graph(60000, 1200000, seed=44, n_classes=9)
+    h = hashlib.sha256(g.edge_index.contiguous().numpy().tobytes() + g.edge_attr.numpy().tobytes() + g.y.numpy().tobytes())
+    assert h.hexdigest()[:16] == "6d6b325ca1a94237"
+    kw = dict(n_nodes=20000, n_edges=400000, seed=44, n_classes=10, n_topics=10, vocab_frac=0.03, doc_word_share=0.9,
+              features="none")
+    gt, gs = synth.word_doc_graph(**kw), synth.word_doc_graph(**kw, doc_order="shuffled")
+    V, D = gt.n_vocab, 20000 - gt.n_vocab
+    assert gt.edge_index.shape == gs.edge_index.shape == (2, 400000)
+    assert float((gt.y[V + 1:] == gt.y[V:-1]).float().mean()) > 0.99 > 0.2 > float((gs.y[V + 1:] == gs.y[V:-1]).float().mean())
+    assert torch.equal(torch.bincount(gt.y[V:], minlength=10), torch.bincount(gs.y[V:], minlength=10))
+    # the same graph up to the numbering of the documents: word-side degrees, weights and the word-word block agree
+    for a, b in ((gt, gs),):
+        wa, wb = a.edge_index[1] < V, b.edge_index[1] < V
+        assert torch.equal(torch.bincount(a.edge_index[1][wa], minlength=V), torch.bincount(b.edge_index[1][wb], minlength=V))
+        assert torch.equal(a.edge_attr.sort().values, b.edge_attr.sort().values)
+
+    def adjacent_jaccard(g):
+        m = (g.edge_index[0] >= V) & (g.edge_index[1] < V)
+        d, w = g.edge_index[0][m] - V, g.edge_index[1][m]
+        order = torch.argsort(d, stable=True)
+        d, w = d[order], w[order]
+        ptr = torch.zeros(D + 1, dtype=torch.long)
+        ptr[1:] = torch.bincount(d, minlength=D).cumsum(0)
+        tot, n = 0.0, 0
+        for i in range(0, D - 1, 37):
+            a, b = set(w[ptr[i]:ptr[i + 1]].tolist()), set(w[ptr[i + 1]:ptr[i + 2]].tolist())
+            tot, n = tot + len(a & b) / max(1, len(a | b)), n + 1
+        return tot / n
+    assert adjacent_jaccard(gt) > 2.0 * adjacent_jaccard(gs)
+    with pytest.raises(ValueError):
+        synth.word_doc_graph(**dict(kw, doc_order="sorted"))
