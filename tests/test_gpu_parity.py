@@ -1194,6 +1194,38 @@ def test_mfma_gemms_match_float64(cuda, N, k, n):
     assert rel_err(dense.gemm_nn(big[:, 4:4 + k], bd), (big[:, 4:4 + k].cpu().double() @ b.double()).float()) < TOL
 
 
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 97, 8191, 70_001])
+@pytest.mark.parametrize("n", [193, 200, 208, 224])
+def test_block_pipelined_nt_kernel_edges(cuda, N, n):
+    """k_gemm_pipe (the class-width input-gradient product, k = 64, 193 .. 224 result columns: operand of block b + 1 in
+    flight under block b's MFMAs; a wave's loop body is TWO blocks): one block, an odd number of blocks per wave, a ragged
+    last block, every column count of its range -- plain and with column sums against float64, and the mask read from
+    the forward product's record bit for bit the hashed kernel's (which is another kernel, k_gemm_tall)."""
+    from pytextgcn_amd import dense
+    gen = torch.Generator(device=cuda).manual_seed(N * 7 + n)
+    g = torch.randn(N, 64, device=cuda, generator=gen)
+    w = torch.randn(n, 64, device=cuda, generator=gen)
+    ref = g.double() @ w.double().t()
+    plain = dense.gemm_nt(g, w)
+    assert rel_err(plain, ref) < TOL
+    noted = dense.gemm_nt(g, w, note_colsums=True)
+    assert torch.equal(noted, plain)
+    assert ((colsum(noted).double() - ref.sum(0)).abs().max() / ref.sum(0).abs().max().clamp_min(1e-30)).item() < 2e-5
+    # through the record: the forward product over the [N, n] activation writes the keep bits, this product reads them
+    p = 0.5
+    seed = dense.new_seed(cuda)
+    h = torch.randn(N, n, device=cuda, generator=gen)
+    _, mask = dense.gemm_nn(h, w, p, seed, record_mask=True)
+    hashed = dense.gemm_nt(g, w, p, seed, note_colsums=True)
+    if mask is not None:
+        rec = dense.gemm_nt(g, w, p, seed, note_colsums=True, mask=mask)
+        assert torch.equal(rec, hashed)
+        want = rec.double().sum(0)
+        assert ((colsum(rec).double() - want).abs().max() / want.abs().max().clamp_min(1e-30)).item() < 2e-5
+    keep = hashed != 0
+    assert rel_err(hashed, ref * keep / (1 - p)) < TOL
+
+
 @pytest.mark.parametrize("N,k,n,p", [(1, 1, 1, 0.0), (31, 7, 3, 0.5), (1000, 64, 200, 0.0), (4097, 10, 200, 0.7),
                                      (100_000, 64, 200, 0.5), (5000, 64, 256, 0.5), (70_001, 32, 100, 0.0)])
 def test_nt_gemm_leaves_the_column_sums_of_its_result(cuda, N, k, n, p):
