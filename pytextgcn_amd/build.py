@@ -68,6 +68,71 @@ def check_asm_ring_kernels(remarks: str) -> None:
                            + "\n  ".join(bad))
 
 
+def scan_pipe_isa(disassembly: str):
+    """(number of k_gemm_pipe functions, violations) in `llvm-objdump -d --no-show-raw-insn` output of the device code: a
+    violation is an instruction that names a destination register of a `global_load_dwordx4` issued earlier in the same
+    function and not yet covered by an `s_waitcnt vmcnt(0)`."""
+    def regs_of(text):
+        out = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", text):
+            out.add(int(m.group(1)))
+        return out
+    name, seen, bad = None, 0, []
+    pending = set()
+    for line in disassembly.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            name, pending = (m.group(1) if "k_gemm_pipe" in m.group(1) else None), set()
+            seen += name is not None
+            continue
+        ins = line.split("//")[0].strip()
+        if name is None or not ins or ins.startswith(";"):
+            continue
+        op = ins.split()[0]
+        if op == "global_load_dwordx4":
+            dst, rest = ins.split(None, 1)[1].split(",", 1)
+            if regs_of(rest) & pending:
+                bad.append(f"{name}: {ins}")
+            pending |= regs_of(dst)
+        elif op == "s_waitcnt" and "vmcnt(0)" in ins:
+            pending = set()
+        elif regs_of(ins) & pending:
+            bad.append(f"{name}: {ins}")
+    return seen, bad
+
+
+def check_pipe_kernel_isa(obj: str) -> str:
+    """k_gemm_pipe keeps inline-asm loads in flight across a whole k-loop (dense.hip): NO instruction may touch a
+    destination register of such a load between its issue and the `s_waitcnt vmcnt(0)` that covers it -- not a use, not a
+    copy the register allocator slipped in.  The spill remarks cannot see a copy; the disassembly can.  The device code is
+    taken out of the object (llvm-objdump --offloading) and every `k_gemm_pipe` function is scanned in program order (its
+    loop bodies are straight-line between the waits).  Returns a one-line summary; raises on a violation; says so and
+    returns when the ROCm binutils are not where expected (the check is then skipped, not failed)."""
+    import glob
+    import tempfile
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return "k_gemm_pipe ISA check skipped: llvm-objdump not found"
+    with tempfile.TemporaryDirectory() as d:
+        local = os.path.join(d, "dense.o")
+        shutil.copy(obj, local)
+        subprocess.run([objdump, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
+        code = glob.glob(os.path.join(d, "dense.o.*gfx950*"))
+        if not code:
+            return "k_gemm_pipe ISA check skipped: no gfx950 bundle extracted"
+        res = subprocess.run([objdump, "-d", "--no-show-raw-insn", code[0]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True)
+    seen, bad = scan_pipe_isa(res.stdout)
+    if seen == 0:
+        raise RuntimeError("build check: no k_gemm_pipe function in the disassembly of dense.o (did the kernel's name change?)")
+    if bad:
+        raise RuntimeError("build check: a register of an inline-asm load in flight is touched before its wait:\n  "
+                           + "\n  ".join(bad[:10]))
+    return f"k_gemm_pipe ISA check: {seen} instantiations, no instruction touches a ring register in flight"
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile what is newer than its object file (one hipcc process per stale source, run side by side),
     then link.  Returns the library path."""
@@ -103,6 +168,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if s == "dense.hip":
                 try:
                     check_asm_ring_kernels(out)
+                    note = check_pipe_kernel_isa(tmp)
+                    if verbose:
+                        print(note, file=sys.stderr)
                 except RuntimeError as e:
                     failed.append(str(e))
                     os.remove(tmp)

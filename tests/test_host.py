@@ -322,6 +322,35 @@ def test_build_refuses_spills_in_the_asm_ring_kernels():
         build.check_asm_ring_kernels(remark(ring, 0, 0).replace("ScratchSize [bytes/lane]", "Scratch bytes per lane"))
 
 
+def test_build_refuses_a_touched_ring_register_of_the_block_pipelined_kernel():
+    """k_gemm_pipe keeps inline-asm loads in flight across a whole k-loop; the build scans its disassembly
+    (pytextgcn_amd/build.py: scan_pipe_isa / check_pipe_kernel_isa) and fails if ANY instruction names a destination
+    register of such a load before the `s_waitcnt vmcnt(0)` that covers it -- a copy slipped in by the register allocator
+    would read stale data without any diagnostic (the spill remarks cannot see it)."""
+    import os
+    from pytextgcn_amd import build
+    head = "0000000000001000 <_ZN4tgcn12_GLOBAL__N_111k_gemm_pipeILi7ELi8ELb1ELb1ELb1EEEvPKf>:\n"
+    good = head + """\tglobal_load_dwordx4 v[10:13], v[2:3], off
+\tglobal_load_dwordx4 v[14:17], v[2:3], off offset:32
+\tv_mfma_f32_32x32x2_f32 v[100:115], v20, v21, v[100:115]
+\ts_waitcnt vmcnt(0)
+\tv_mfma_f32_32x32x2_f32 v[100:115], v10, v21, v[100:115]
+\tglobal_store_dword v[4:5], v100, off
+"""
+    assert build.scan_pipe_isa(good) == (1, [])
+    copied = good.replace("\tv_mfma_f32_32x32x2_f32 v[100:115], v20, v21, v[100:115]\n", "\tv_mov_b32_e32 v30, v12\n", 1)
+    seen, bad = build.scan_pipe_isa(copied)
+    assert seen == 1 and len(bad) == 1 and "v_mov_b32_e32 v30, v12" in bad[0]
+    used_as_address = good.replace("v[14:17], v[2:3], off offset:32", "v[14:17], v[10:11], off")
+    assert len(build.scan_pipe_isa(used_as_address)[1]) == 1
+    other = good.replace("k_gemm_pipe", "k_gemm_tall")                 # other kernels are not this check's business
+    assert build.scan_pipe_isa(other.replace("v20, v21", "v12, v21")) == (0, [])
+    obj = os.path.join(build.OBJ_DIR, "dense.o")
+    if os.path.exists(obj):                                            # the object of this checkout's own build
+        note = build.check_pipe_kernel_isa(obj)
+        assert "skipped" in note or "no instruction touches" in note, note
+
+
 def test_counter_traffic_on_file_belongs_to_the_current_kernels():
     """bench.py quotes the L2 <-> fabric bytes of one tgcn_spmm launch from profiles/traffic.json, a constant collected
     with rocprofv3 counters.  It is only valid for the kernels it was collected on: the record carries a fingerprint
