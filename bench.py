@@ -337,6 +337,16 @@ def is_device_error(e) -> bool:
     return isinstance(e, RuntimeError) and any(w in text for w in _DEVICE_ERROR_WORDS)
 
 
+_T0 = time.time()
+
+
+def note(msg, rank=0):
+    """A progress line on STDERR (stdout carries the one JSON line): long configurations (c5: minutes of host-side work in
+    the CPU legs and the counter passes) must not look hung to whoever watches the run."""
+    if rank == 0:
+        print(f"bench.py [{time.time() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -405,6 +415,8 @@ def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5, full="auto", ref_bud
         t0 = time.perf_counter()
         O.propagate(fwd, x, w, N)
         O.propagate(bwd, x, w, N)
+        if time.perf_counter() - t0 > 20.0:
+            note(f"CPU-ref repetition {rep + 1} of at most {warm_ref + reps_ref}")
         if rep >= warm_ref:
             times.append(time.perf_counter() - t0)
             if run_full and time.perf_counter() - t_leg > ref_budget_s:
@@ -426,6 +438,7 @@ def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5, full="auto", ref_bud
     def csr(rp_, col_, val_):
         lib.oracle_csr_spmm_f32(N, rp_.data_ptr(), col_.data_ptr(), val_.data_ptr(), x.data_ptr(), x.stride(0), F,
                                 None, y.data_ptr(), y.stride(0))
+    note(f"CPU-ref done ({t_ref:.2f} s per pair); CPU-csr on the full operator")
     times = []
     for rep in range(warm + reps):
         t0 = time.perf_counter()
@@ -433,6 +446,8 @@ def cpu_baseline(plan, F, frac, E, seed=44, warm=3, reps=5, full="auto", ref_bud
         csr(rpt, colt, valt)
         if rep >= warm:
             times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t0 > 20.0:
+            note(f"CPU-csr repetition {rep + 1} of {warm + reps}")
     t_csr = sorted(times)[len(times) // 2]
     threads = torch.get_num_threads()
     return {"value": 2.0 * n_edges / t_ref, "unit": "edges/s", "cores": threads, "kind": "port",
@@ -900,6 +915,7 @@ def main():
         g = Data(x=None, edge_index=coo.t(), edge_attr=attr, n_vocab=int(meta.item()))
     torch.cuda.synchronize()
     setup_s["graph_generation" + ("_and_broadcast" if world > 1 else "")] = round(time.perf_counter() - t_setup, 3)
+    note(f"graph {args.config} generated", rank)
     t_setup = time.perf_counter()
     gen = torch.Generator(device=dev).manual_seed(1234)
     bias = torch.randn(F, device=dev, generator=gen)
@@ -1048,7 +1064,9 @@ def main():
             dt = t.item()
         return (dt, sum(e[0].elapsed_time(e[1]) for e in events) / args.steps,
                 sum(e[1].elapsed_time(e[2]) for e in events) / args.steps)
+    note("operators built; timing the headline", rank)
     elapsed, ms_fwd, ms_bwd = timed(step)
+    note(f"headline timed: {elapsed / args.steps * 1e3:.3f} ms per step", rank)
     launch_ms = 0.5 * (ms_fwd + ms_bwd)
     # the accurate mode beside it: same graph, same operands, same K / W, same bracket (N = 1)
     other_mode = None
@@ -1118,6 +1136,7 @@ def main():
     # what the SpMM pulls from HBM, measured live on this box (outside the timed region; N = 1 only: at N > 1
     # the step contains collectives every rank must enter)
     hbm = hbm_activity(step, dev) if (world == 1 and not force_sharded and not args.no_hbm_activity) else None
+    note("memory-controller activity measured; secondary measurements follow", rank)
 
     def secondary(name, fn):
         """One guarded secondary measurement; the headline is complete before the first of them.
@@ -1131,6 +1150,7 @@ def main():
             launcher (launch_ranks) runs the plain configuration in a fresh child."""
         import pytextgcn_amd as pkg
         from pytextgcn_amd import dense as _dense
+        note(f"secondary: {name}", rank)
         try:
             if os.environ.get("TGCN_BENCH_TEST_FAIL") == "secondary" and world > 1 and rank == world - 1 \
                     and name == "exchange_diagnostics":
@@ -1209,7 +1229,8 @@ def main():
         if parallelism == "single" and not args.no_live_traffic and not args.no_hbm_activity:
             # the counters of THIS run's library on THIS box (two short child runs under rocprofv3), so that `traffic` is
             # not a constant the builder committed; the committed figure stays in the record beside it
-            live, live_note = live_fabric_traffic(args.config, headline_mode)
+            note("counter passes (two child runs under rocprofv3 --pmc)")
+            live, live_note = live_fabric_traffic(args.config, headline_mode, timeout_s=300 if args.config == "c5" else 90)
             if live is not None:
                 fabric, fabric_src, fabric_fresh = live, live_note, True
         hbm_bytes = None
@@ -1316,6 +1337,7 @@ def main():
             "setup_s": setup_s,
         })
         if world == 1 and not args.no_cpu_baseline and not force_sharded:
+            note("CPU baselines (reference formulation, then the C CSR oracle)")
             out["cpu_baseline"] = cpu_baseline(plan, F, args.cpu_sample_frac, E,
                                                full={"auto": "auto", "full": True, "sample": False}[args.cpu_ref])
         write_record(out)
