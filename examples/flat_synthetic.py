@@ -45,12 +45,14 @@ g = g.to(device)                                                       # :86
 Opt = optim.Adam if args.fused else th.optim.Adam
 optimizer = Opt(gcn.parameters(), lr=lr, amsgrad=True)                 # :89
 
+rows_eval = g.val_mask | g.train_mask          # --fused: the last layer computes only the logits rows that are read (kept tensors:
+rows_train = g.train_mask                      # the restricted operators are cached under them)
 th.cuda.synchronize()
 t0 = time.time()
 for epoch in range(args.epochs):                                       # :99-117
     gcn.train()
     if args.fused:
-        loss = functional.masked_cross_entropy(gcn(g), g.y, g.train_mask)
+        loss = functional.masked_cross_entropy(gcn(g, rows=rows_train), g.y, g.train_mask)
     else:
         outputs = gcn(g)[g.train_mask]
         loss = criterion(outputs, g.y[g.train_mask])
@@ -59,7 +61,7 @@ for epoch in range(args.epochs):                                       # :99-117
     optimizer.step()
     gcn.eval()
     with th.no_grad():
-        logits = gcn(g)
+        logits = gcn(g, rows=rows_eval) if args.fused else gcn(g)
         pred_val = np.argmax(logits[g.val_mask].cpu().numpy(), axis=1)
         pred_train = np.argmax(logits[g.train_mask].cpu().numpy(), axis=1)
         f1_val = f1_score(g.y.cpu()[g.val_mask.cpu()], pred_val, average="macro")

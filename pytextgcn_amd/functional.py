@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .plan import _require_cuda, _stream_ptr, alloc_padded, note_colsum, padded_base
+from .plan import _require_cuda, _stream_ptr, alloc_padded, note_colsum, note_zero_rows, padded_base
 
 _COUNT_CACHE: dict = {}
 
@@ -123,6 +123,7 @@ class _MaskedCE(torch.autograd.Function):
     def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count, want_pred: bool):
         loss, grads, pred = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count, want_pred)
         ctx.save_for_backward(*(grads if grads is not None else ()))
+        ctx.mask = mask
         if not want_pred:
             return loss
         ctx.mark_non_differentiable(pred)
@@ -151,6 +152,9 @@ class _MaskedCE(torch.autograd.Function):
             note_colsum(base, torch.as_strided(dbias, (base.size(1),), (1,)))     # dbias was cut from zeros(C4)
         else:
             note_colsum(dlogits, dbias)
+        # every row the mask does not select is exactly zero (the kernel wrote 0.f there; scaling keeps it): the propagate
+        # step that takes this gradient may skip those operand rows (plan.known_nonzero_rows)
+        note_zero_rows(base if base is not None else dlogits, ctx.mask)
         return dlogits, None, None, None, None
 
 

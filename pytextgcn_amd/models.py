@@ -51,7 +51,7 @@ class GCN(nn.Module):
             self.layers.append(GCNConv(n_hidden_gcn, n_hidden_gcn, add_self_loops=True))
         self.layers.append(GCNConv(n_hidden_gcn, out_channels, add_self_loops=True))
 
-    def _collapsed_forward(self, g):
+    def _collapsed_forward(self, g, rows=None):
         layers = list(self.layers)
         tail = [None] * len(layers)            # tail[i] = W_{i+1} ... W_L (None = identity)
         for i in range(len(layers) - 2, -1, -1):
@@ -62,18 +62,28 @@ class GCN(nn.Module):
             b = layer.bias
             if b is not None and tail[i] is not None:
                 b = dense.xw(b.unsqueeze(0), tail[i]).squeeze(0)      # a 1-row product: still no vendor GEMM
-            z = propagate(layer.plan(g.x, g.edge_index, g.edge_attr), z, b)
+            plan = layer.plan(g.x, g.edge_index, g.edge_attr)
+            if rows is not None and i == len(layers) - 1:
+                plan = plan.on_rows(rows) or plan
+            z = propagate(plan, z, b)
         return z
 
-    def forward(self, g):
+    def forward(self, g, rows=None):
+        """`rows` (an extension of the reference's signature; a bool mask over the nodes that the caller keeps): the rows of
+        the logits that will be READ -- `g.train_mask` in the training step (flat_amazon.py:101 indexes the output with it),
+        the validation and training rows in evaluation (:109-114).  The LAST layer's propagate step then runs on the
+        operator restricted to them; every other row of the result holds the last layer's bias.  In a TextGCN graph the
+        word rows, which nobody reads, hold two thirds of the operator's entries."""
         if (_COLLAPSE and len(self.layers) > 1 and not torch.is_grad_enabled()
                 and (not self.training or self.dropout == 0)):
-            return self._collapsed_forward(g)
+            return self._collapsed_forward(g, rows)
         x = g.x
         pending = 0.0                          # dropout still owed to x (fused into the next layer)
+        last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x, g.edge_index, g.edge_attr, input_dropout=pending) if pending > 0.0 \
-                else layer(x, g.edge_index, g.edge_attr)
+            kw = {"rows": rows} if (rows is not None and i == last) else {}
+            x = layer(x, g.edge_index, g.edge_attr, input_dropout=pending, **kw) if pending > 0.0 \
+                else layer(x, g.edge_index, g.edge_attr, **kw)
             pending = 0.0
             if i < len(self.layers) - 1:
                 if _FUSED_DROPOUT and self.training and 0.0 < self.dropout < 1.0 and not x.is_sparse:

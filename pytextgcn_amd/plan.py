@@ -187,6 +187,58 @@ class GraphPlan:
             cache[key] = ws
         return ws if ws is not False else None
 
+    def transposed_on_rows(self, keep: Tensor, max_share: float = 0.85) -> Optional["GraphPlan"]:
+        """M^T restricted to the COLUMNS (operand rows) `keep` selects: the operator that gives M^T @ g for every g whose
+        other rows are exactly zero.  Built once per (plan, mask) from this plan's own transposed CSR (same entries, same
+        order within a row) and kept; None when the mask keeps more than `max_share` of the entries (nothing to gain), or
+        while a HIP graph is being captured and the operator is not there yet (it allocates and synchronises)."""
+        cache = self.__dict__.setdefault("_restricted_t", {})
+        key = (keep.data_ptr(), keep._version, keep.numel())
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[0]
+        if torch.cuda.is_current_stream_capturing() or keep.dtype != torch.bool or keep.device != self.device \
+                or keep.numel() != (self.n_cols_t):
+            return None
+        rowptr, col, val = self.export_csr(transpose=True)
+        sel = keep[col.long()]
+        kept = int(sel.sum().item())
+        op = None
+        if kept <= max_share * max(1, col.numel()):
+            row = torch.repeat_interleave(torch.arange(self.n_rows_t, device=self.device), (rowptr[1:] - rowptr[:-1]).long())
+            op = GraphPlan.from_coo(row[sel], col[sel].long(), val[sel], self.n_rows_t, self.n_cols_t)
+        if len(cache) >= 4:
+            cache.clear()
+        cache[key] = (op, keep)                      # (the entry holds the mask: its address cannot be recycled under the key)
+        return op
+
+    def on_rows(self, keep: Tensor, max_share: float = 0.85) -> Optional["GraphPlan"]:
+        """M restricted to the ROWS `keep` selects (with its transpose): the operator whose product equals M @ x on those
+        rows and leaves every other row at the bias.  For a LAST layer whose other rows nobody reads -- the loss sees
+        `out[g.train_mask]` only (flat_amazon.py:101), the metrics the validation and training rows (:109-114); the word
+        rows, which nobody reads, hold two thirds of a TextGCN operator's entries.  Built once per (plan, mask) from this
+        plan's own CSR (same entries, same order within a row) and kept; None when the mask keeps more than `max_share` of
+        the entries, or while a HIP graph is being captured and the operator is not there yet."""
+        cache = self.__dict__.setdefault("_restricted_rows", {})
+        key = (keep.data_ptr(), keep._version, keep.numel())
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[0]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if keep.dtype != torch.bool or keep.device != self.device or keep.numel() != self.n_rows:
+            raise ValueError(f"rows: a bool mask of {self.n_rows} entries on {self.device} is required")
+        rowptr, col, val = self.export_csr()
+        row = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), (rowptr[1:] - rowptr[:-1]).long())
+        sel = keep[row]
+        op = None
+        if int(sel.sum().item()) <= max_share * max(1, col.numel()):
+            op = GraphPlan.from_coo(row[sel], col[sel].long(), val[sel], self.n_rows, self.n_cols, with_transpose=True)
+        if len(cache) >= 4:
+            cache.clear()
+        cache[key] = (op, keep)                      # (the entry holds the mask: its address cannot be recycled under the key)
+        return op
+
     # -- compute ----------------------------------------------------------------------------
     def spmm(self, x: Tensor, bias: Optional[Tensor] = None, transpose: bool = False,
              out: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
@@ -324,6 +376,45 @@ def _known_colsum(g: Tensor) -> Optional[Tensor]:
     if g.dim() == 2 and len(hit[1]) == 2 and g.size(0) == hit[1][0] and g.size(1) < hit[1][1] and g.stride() == t.stride():
         return hit[3][:g.size(1)]
     return None
+
+
+# Rows a producer kernel knows to be EXACTLY zero.  `tgcn_masked_ce_grad` writes 0.f into every row of the logits'
+# gradient that the loss mask does not select (flat_amazon.py:101-102: the loss sees `out[g.train_mask]` only) -- at c4 that
+# is every word node and the validation / test documents, 28 % of the rows -- and the propagate step that consumes the
+# gradient, dXW2 = M^T dOut, gathers those rows once per entry like any other.  The note lets it use M^T restricted to the
+# columns that can contribute (GraphPlan.transposed_on_rows).  Keyed and validated like the column-sum notes.
+_KNOWN_ZERO_ROWS: dict = {}
+_SKIP_ZERO_ROWS = __import__("os").environ.get("TGCN_SKIP_ZERO_ROWS", "1") != "0"      # (A/B runs: TGCN_SKIP_ZERO_ROWS=0)
+
+
+def enable_zero_row_skipping(on: bool = True) -> bool:
+    """The backward propagate step of a gradient whose zero rows are known (the fused cross-entropy's) runs on the
+    operator restricted to the non-zero rows (default: on).  Returns the previous setting."""
+    global _SKIP_ZERO_ROWS
+    prev, _SKIP_ZERO_ROWS = _SKIP_ZERO_ROWS, bool(on)
+    return prev
+
+
+def note_zero_rows(t: Tensor, keep: Tensor) -> None:
+    """Record that row r of `t` is exactly zero wherever `keep[r]` is False, for `t` and `keep` as they are now."""
+    import weakref
+    key = t.data_ptr()
+    _KNOWN_ZERO_ROWS[key] = (weakref.ref(t, lambda _, k=key: _KNOWN_ZERO_ROWS.pop(k, None)), t.size(0), t._version, keep,
+                             keep._version)
+
+
+def known_nonzero_rows(g: Tensor) -> Optional[Tensor]:
+    """The bool mask of the rows of `g` that may be non-zero, if its producer left one (else None)."""
+    if not _SKIP_ZERO_ROWS:
+        return None
+    hit = _KNOWN_ZERO_ROWS.get(g.data_ptr())
+    if hit is None:
+        return None
+    t = hit[0]()
+    if t is None or t.data_ptr() != g.data_ptr() or g.dim() != 2 or g.size(0) != hit[1] or hit[2] != g._version \
+            or t._version != g._version or hit[3]._version != hit[4] or hit[3].numel() != g.size(0):
+        return None
+    return hit[3]
 
 
 def colsum(g: Tensor) -> Tensor:

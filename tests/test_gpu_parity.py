@@ -1025,6 +1025,95 @@ def test_fused_training_loop_tracks_the_oracle(cuda):
         assert rel_err(z_m, z_r) < 1e-3, step
 
 
+@pytest.mark.parametrize("fused_dropout", [False, True])
+def test_last_layer_computes_only_the_rows_that_are_read(cuda, fused_dropout):
+    """`GCN.forward(g, rows=mask)`: the last layer's propagate step on the operator restricted to the rows the caller will
+    read (GraphPlan.on_rows).  On those rows the logits are the full forward's (to rounding: another work partition), every
+    other row holds the last layer's bias; the loss over the mask and every gradient agree with the full forward's and
+    with the oracle's; the eval forward (and the collapsed one) likewise."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.plan import plan_for
+    N, C = 12000, 8
+    g = synth.word_doc_graph(N, 200000, seed=32, n_classes=C)
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    torch.manual_seed(6)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=200, dropout=0.0)
+    with torch.no_grad():
+        ref.layers[1].bias.normal_(0, 0.3)
+    lo_r = ref(g)
+    torch.nn.CrossEntropyLoss()(lo_r[g.train_mask], g.y[g.train_mask]).backward()
+    m = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(cuda).float()
+    pkg.enable_fused_dropout(fused_dropout)                    # (p = 0: the fused path must take the option as well)
+    try:
+        full = m(gd)
+        part = m(gd, rows=gd.train_mask)
+        keep = gd.train_mask
+        assert rel_err(part[keep], full[keep]) < 2e-6 and rel_err(part[keep], lo_r[g.train_mask]) < TOL
+        assert torch.equal(part[~keep], m.layers[1].bias.detach().expand(int((~keep).sum()), C))
+        loss = masked_cross_entropy(part, gd.y, gd.train_mask)
+        loss.backward()
+        for (name, pr), pm in zip(ref.named_parameters(), m.parameters()):
+            assert rel_err(pm.grad, pr.grad) < 5 * TOL, name
+        op = plan_for(gd.edge_index, gd.edge_attr, N).on_rows(gd.train_mask)
+        assert op is not None and op.nnz < 0.5 * (200000 + N)                       # the word rows are gone
+        m.eval()
+        rows_eval = gd.val_mask | gd.train_mask
+        with torch.no_grad():
+            ev_full, ev_part = m(gd), m(gd, rows=rows_eval)
+            assert rel_err(ev_part[rows_eval], ev_full[rows_eval]) < 2e-6
+            pkg.enable_linear_collapse(True)
+            assert rel_err(m(gd, rows=rows_eval)[rows_eval], ev_full[rows_eval]) < TOL
+    finally:
+        pkg.enable_fused_dropout(False)
+        pkg.enable_linear_collapse(False)
+    with pytest.raises(ValueError):
+        m(gd, rows=gd.train_mask[:-1])
+
+
+def test_backward_propagate_skips_the_rows_the_loss_mask_leaves_zero(cuda):
+    """The fused cross-entropy writes exact zeros into every gradient row its mask does not select (all word nodes, the
+    validation / test documents: flat_amazon.py:101-102) and says so (plan.note_zero_rows); the propagate step that
+    consumes the gradient then runs M^T restricted to the other columns (GraphPlan.transposed_on_rows) -- the same sums
+    without the zero terms.  Gradients with and without the restriction agree to rounding and both meet the oracle;
+    a mask that keeps (nearly) everything gets no restricted operator; the switch turns it off."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.plan import plan_for
+    N, C = 12000, 8
+    g = synth.word_doc_graph(N, 200000, seed=31, n_classes=C)
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    torch.manual_seed(4)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=200, dropout=0.0)
+    lo_r = ref(g)
+    torch.nn.CrossEntropyLoss()(lo_r[g.train_mask], g.y[g.train_mask]).backward()
+    grads = {}
+    for on in (True, False):
+        prev = pkg.enable_zero_row_skipping(on)
+        try:
+            m = pkg.GCN(N, C, n_hidden_gcn=200, dropout=0.0)
+            m.load_state_dict(ref.state_dict())
+            m = m.to(cuda).float()
+            masked_cross_entropy(m(gd), gd.y, gd.train_mask).backward()
+            grads[on] = [p.grad.clone() for p in m.parameters()]
+        finally:
+            pkg.enable_zero_row_skipping(prev)
+    plan = plan_for(gd.edge_index, gd.edge_attr, N)
+    ops = [v[0] for v in plan.__dict__.get("_restricted_t", {}).values()]
+    assert len(ops) == 1 and ops[0] is not None and ops[0].nnz < 0.8 * plan.nnz_t          # words and held-out documents gone
+    for a, b, (name, pr) in zip(grads[True], grads[False], ref.named_parameters()):
+        assert rel_err(a, b) < 2e-6, name
+        assert rel_err(a, pr.grad) < 5 * TOL and rel_err(b, pr.grad) < 5 * TOL, name
+    # the restricted operator IS M^T with the unselected columns dropped: on a gradient that is zero there, the same product
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.randn(N, 64, device=cuda, generator=gen) * gd.train_mask.unsqueeze(1)
+    assert rel_err(ops[0].spmm(x), plan.spmm(x, transpose=True)) < 2e-6
+    assert row_rel_err(ops[0].spmm(x), plan.spmm(x, transpose=True)) < 1e-5
+    # a mask that keeps everything: nothing to gain, no second operator
+    everything = torch.ones(N, dtype=torch.bool, device=cuda)
+    assert plan.transposed_on_rows(everything) is None
+
+
 # ------------------------------------------------------------------------------------------------
 # dense X @ W on the fp32 matrix cores
 # ------------------------------------------------------------------------------------------------
