@@ -77,6 +77,76 @@ def test_config_c4_reference_order_mode_reproduces_the_oracles_weights_and_meets
     assert e < TOL and e_row < TOL, (e, e_row)
 
 
+def test_config_c4_training_step_gradients_against_the_oracle_at_full_size(cuda, c4case):
+    """One training step of flat_amazon.py:99-105 at BASELINE.json's c4 size in the package-default mode -- GCN(N -> 200
+    -> 64), CrossEntropyLoss(mean) over the training rows, backward -- against the ORACLE's operator end to end: the C CSR
+    oracle (float64 accumulation) on the oracle's normalisation of the 50 M edges, float64 GEMMs and loss on the host.  Loss,
+    logits on the training rows and ALL FOUR gradients (dW1: 2 M x 200; db1; dW2; db2) at 1e-5; dW1 additionally row by row
+    on the 64 heaviest rows.  Both forms of the step: the plain forward, and `gcn(g, rows=train_mask)` (the last layer
+    computes only the rows the loss reads); the backward propagate step skips the gradient rows the loss leaves zero in
+    both.  No dropout (the oracle has no access to the device's mask)."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    N, F, C = c4case.N, 200, 64
+    g = c4case.g
+    gen = torch.Generator().manual_seed(21)
+    y_cpu = torch.randint(0, C, (N,), generator=gen)
+    n_vocab = N // 10
+    mask_cpu = (torch.rand(N, generator=gen) < 0.8) & (torch.arange(N) >= n_vocab)        # documents only (text2graph.py:180-188)
+    y, mask = y_cpu.to(cuda), mask_cpu.to(cuda)
+    torch.manual_seed(9)
+    model = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.0).to(cuda).float()
+    with torch.no_grad():
+        model.layers[0].bias.normal_(0, 0.1)
+        model.layers[1].bias.normal_(0, 0.1)
+    ar = torch.arange(N, device=cuda)
+    eye = torch.sparse_coo_tensor(torch.stack([ar, ar]), torch.ones(N, device=cuda), (N, N)).coalesce()
+    data = pkg.Data(x=eye, edge_index=g.edge_index, edge_attr=g.edge_attr)
+    w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
+                                                 model.layers[1].weight, model.layers[1].bias))
+    # ---- the oracle's step (host): M and M^T as CSR of the oracle's own weights
+    rp, col, val, _ = c4case.oracle_csr()
+    tgt, src, nw = c4case.oracle_coo()
+    order_t = torch.argsort(src * N + tgt, stable=True)
+    rpt = torch.zeros(N + 1, dtype=torch.int64)
+    rpt[1:] = torch.bincount(src, minlength=N).cumsum(0)
+    colt, valt = tgt[order_t].to(torch.int32), nw[order_t].contiguous()
+    del order_t, tgt, src, nw
+    h1 = csr_oracle.csr_spmm(rp, col, val, w1, b1, acc64=True)
+    xw2 = (h1.double() @ w2.double()).float()
+    logits_ref = csr_oracle.csr_spmm(rp, col, val, xw2, b2, acc64=True)
+    lg = logits_ref[mask_cpu].double().requires_grad_()
+    loss_ref = torch.nn.functional.cross_entropy(lg, y_cpu[mask_cpu])
+    loss_ref.backward()
+    dlogits = torch.zeros(N, C, dtype=torch.float32)
+    dlogits[mask_cpu] = lg.grad.float()
+    db2_ref = dlogits.double().sum(0)
+    dxw2 = csr_oracle.csr_spmm(rpt, colt, valt, dlogits, acc64=True)
+    dw2_ref = h1.double().t() @ dxw2.double()
+    dh1 = (dxw2.double() @ w2.double().t()).float()
+    db1_ref = dh1.double().sum(0)
+    dw1_ref = csr_oracle.csr_spmm(rpt, colt, valt, dh1, acc64=True)
+    del dh1, dxw2, xw2
+    heavy = (rpt[1:] - rpt[:-1]).topk(64).indices
+    for use_rows in (False, True):
+        model.zero_grad(set_to_none=True)
+        model.train()
+        out = model(data, rows=mask) if use_rows else model(data)
+        loss = masked_cross_entropy(out, y, mask)
+        loss.backward()
+        torch.cuda.synchronize()
+        tag = "rows" if use_rows else "plain"
+        e_loss = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+        e_out = rel_err(out.detach()[mask], logits_ref[mask_cpu])
+        grads = {"dW1": (model.layers[0].weight.grad, dw1_ref), "db1": (model.layers[0].bias.grad, db1_ref),
+                 "dW2": (model.layers[1].weight.grad, dw2_ref), "db2": (model.layers[1].bias.grad, db2_ref)}
+        errs = {k: rel_err(a, b) for k, (a, b) in grads.items()}
+        e_rows = row_rel_err(model.layers[0].weight.grad[heavy.to(cuda)], dw1_ref[heavy])
+        _report(f"c4_training_step_{tag}", loss_rel=e_loss, logits_on_training_rows=e_out, dW1_heaviest_rows_row_relative=e_rows,
+                **errs)
+        assert e_loss < TOL and e_out < TOL, (tag, e_loss, e_out)
+        assert max(errs.values()) < TOL and e_rows < TOL, (tag, errs, e_rows)
+
+
 # ------------------------------------------------------------------------------------------------
 # the 1-D partition at size
 # ------------------------------------------------------------------------------------------------
