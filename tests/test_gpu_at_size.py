@@ -77,20 +77,15 @@ def test_config_c4_reference_order_mode_reproduces_the_oracles_weights_and_meets
     assert e < TOL and e_row < TOL, (e, e_row)
 
 
-def test_config_c4_training_step_gradients_against_the_oracle_at_full_size(cuda, c4case):
-    """One training step of flat_amazon.py:99-105 at BASELINE.json's c4 size in the package-default mode -- GCN(N -> 200
-    -> 64), CrossEntropyLoss(mean) over the training rows, backward -- against the ORACLE's operator end to end: the C CSR
-    oracle (float64 accumulation) on the oracle's normalisation of the 50 M edges, float64 GEMMs and loss on the host.  Loss,
-    logits on the training rows and ALL FOUR gradients (dW1: 2 M x 200; db1; dW2; db2) at 1e-5; dW1 additionally row by row
-    on the 64 heaviest rows.  Both forms of the step: the plain forward, and `gcn(g, rows=train_mask)` (the last layer
-    computes only the rows the loss reads); the backward propagate step skips the gradient rows the loss leaves zero in
-    both.  No dropout (the oracle has no access to the device's mask)."""
+def _training_step_parity(cuda, g, N, F, C, n_vocab, oracle_coo, case):
+    """One training step (flat_amazon.py:99-105: forward, CrossEntropyLoss(mean) over the training rows, backward) of GCN(N ->
+    F -> C) in the package-default mode against the ORACLE's operator end to end: the C CSR oracle (float64 accumulation)
+    on the oracle's normalisation, float64 GEMMs and loss on the host.  Loss, logits on the training rows and ALL FOUR
+    gradients at 1e-5; dW1 additionally row by row on the 64 heaviest rows.  Both forms of the step: the plain forward, and
+    `gcn(g, rows=train_mask)`; the backward propagate step skips the gradient rows the loss leaves zero in both."""
     from pytextgcn_amd.functional import masked_cross_entropy
-    N, F, C = c4case.N, 200, 64
-    g = c4case.g
     gen = torch.Generator().manual_seed(21)
     y_cpu = torch.randint(0, C, (N,), generator=gen)
-    n_vocab = N // 10
     mask_cpu = (torch.rand(N, generator=gen) < 0.8) & (torch.arange(N) >= n_vocab)        # documents only (text2graph.py:180-188)
     y, mask = y_cpu.to(cuda), mask_cpu.to(cuda)
     torch.manual_seed(9)
@@ -104,13 +99,15 @@ def test_config_c4_training_step_gradients_against_the_oracle_at_full_size(cuda,
     w1, b1, w2, b2 = (t.detach().cpu() for t in (model.layers[0].weight, model.layers[0].bias,
                                                  model.layers[1].weight, model.layers[1].bias))
     # ---- the oracle's step (host): M and M^T as CSR of the oracle's own weights
-    rp, col, val, _ = c4case.oracle_csr()
-    tgt, src, nw = c4case.oracle_coo()
-    order_t = torch.argsort(src * N + tgt, stable=True)
-    rpt = torch.zeros(N + 1, dtype=torch.int64)
-    rpt[1:] = torch.bincount(src, minlength=N).cumsum(0)
-    colt, valt = tgt[order_t].to(torch.int32), nw[order_t].contiguous()
-    del order_t, tgt, src, nw
+    tgt, src, nw = oracle_coo
+    csr = []
+    for a_, b_ in ((tgt, src), (src, tgt)):
+        order = torch.argsort(a_ * N + b_, stable=True)
+        rp_ = torch.zeros(N + 1, dtype=torch.int64)
+        rp_[1:] = torch.bincount(a_, minlength=N).cumsum(0)
+        csr.append((rp_, b_[order].to(torch.int32), nw[order].contiguous()))
+        del order
+    (rp, col, val), (rpt, colt, valt) = csr
     h1 = csr_oracle.csr_spmm(rp, col, val, w1, b1, acc64=True)
     xw2 = (h1.double() @ w2.double()).float()
     logits_ref = csr_oracle.csr_spmm(rp, col, val, xw2, b2, acc64=True)
@@ -139,12 +136,28 @@ def test_config_c4_training_step_gradients_against_the_oracle_at_full_size(cuda,
         e_out = rel_err(out.detach()[mask], logits_ref[mask_cpu])
         grads = {"dW1": (model.layers[0].weight.grad, dw1_ref), "db1": (model.layers[0].bias.grad, db1_ref),
                  "dW2": (model.layers[1].weight.grad, dw2_ref), "db2": (model.layers[1].bias.grad, db2_ref)}
-        errs = {k: rel_err(a, b) for k, (a, b) in grads.items()}
+        errs = {k: rel_err(a_, b_) for k, (a_, b_) in grads.items()}
         e_rows = row_rel_err(model.layers[0].weight.grad[heavy.to(cuda)], dw1_ref[heavy])
-        _report(f"c4_training_step_{tag}", loss_rel=e_loss, logits_on_training_rows=e_out, dW1_heaviest_rows_row_relative=e_rows,
-                **errs)
+        _report(f"{case}_training_step_{tag}", loss_rel=e_loss, logits_on_training_rows=e_out,
+                dW1_heaviest_rows_row_relative=e_rows, **errs)
         assert e_loss < TOL and e_out < TOL, (tag, e_loss, e_out)
         assert max(errs.values()) < TOL and e_rows < TOL, (tag, errs, e_rows)
+
+
+def test_config_c4_training_step_gradients_against_the_oracle_at_full_size(cuda, c4case):
+    """BASELINE.json's headline configuration (2 M nodes, 50 M edges), GCN(N -> 200 -> 64): dW1 is 2 M x 200."""
+    _training_step_parity(cuda, c4case.g, c4case.N, 200, 64, c4case.N // 10, c4case.oracle_coo(), "c4")
+
+
+def test_config_c3_training_step_gradients_against_the_oracle_at_full_size(cuda):
+    """The DBpedia-shaped configuration (1 M nodes, 30 k words, 24 M edges) with its 219 classes (flat_dbpedia.py:80): the
+    class width is no multiple of 4 (zero-padded buffers), the layer-2 products run as column groups."""
+    from oracle import gcn_oracle as O
+    from pytextgcn_amd import synth
+    N, E = 1_000_000, 24_000_000
+    g = synth.word_doc_graph(N, E, seed=44, device=cuda, vocab_frac=0.03, doc_word_share=0.9, features="none")
+    coo = O.normalized_coo(g.edge_index.cpu(), g.edge_attr.cpu(), N)
+    _training_step_parity(cuda, g, N, 200, 219, g.n_vocab, coo, "c3")
 
 
 # ------------------------------------------------------------------------------------------------
