@@ -416,6 +416,43 @@ def test_training_steps_track_the_oracle(cuda):
         assert rel_err(z_m, z_r) < 1e-3, step           # Adam's 1/sqrt(v) amplifies fp32 noise
 
 
+def test_config_c2_training_step_against_the_reference_formulation_itself(cuda):
+    """BASELINE.json configs[1] (100 k nodes, 2 M edges, hidden 200, 64 classes) through the REFERENCE FORMULATION, not its CSR
+    restatement: oracle/gcn_oracle.py `GCNOracle` is PyG-1.6.3's gcn_norm -> x @ W -> index_select / scale / index_add
+    -> + bias with torch autograd, as textgcn/lib/models.py:17-25 runs it on the CPU (it materialises the two 2.1 M x 200
+    message temporaries, which still fit at this size).  One step of flat_amazon.py:99-105: the loss, the logits of ALL rows
+    and every gradient at 1e-5, with the reference's own loss operator (the import-swap path) and with the fused one."""
+    from pytextgcn_amd.functional import masked_cross_entropy
+    N, E, F, C = 100_000, 2_000_000, 200, 64
+    g = synth.word_doc_graph(N, E, seed=44, n_classes=C)
+    torch.manual_seed(17)
+    ref = O.GCNOracle(N, C, n_hidden_gcn=F, dropout=0.0)
+    with torch.no_grad():
+        ref.layers[0].bias.normal_(0, 0.1)
+        ref.layers[1].bias.normal_(0, 0.1)
+    lo_r = ref(g)
+    loss_r = torch.nn.CrossEntropyLoss()(lo_r[g.train_mask], g.y[g.train_mask])
+    loss_r.backward()
+    gd = pkg.Data(**{k: getattr(g, k) for k in g.keys}).to(cuda)
+    for fused in (False, True):
+        mine = pkg.GCN(N, C, n_hidden_gcn=F, dropout=0.0)
+        mine.load_state_dict(ref.state_dict())
+        mine = mine.to(cuda).float()
+        lo_m = mine(gd)
+        if fused:
+            loss_m = masked_cross_entropy(lo_m, gd.y, gd.train_mask)
+        else:
+            loss_m = torch.nn.CrossEntropyLoss()(lo_m[gd.train_mask], gd.y[gd.train_mask])      # flat_amazon.py:101-102
+        loss_m.backward()
+        e_loss = abs(loss_m.item() - loss_r.item()) / abs(loss_r.item())
+        e_out, e_out_rows = rel_err(lo_m, lo_r), row_rel_err(lo_m, lo_r)
+        errs = {k: rel_err(pm.grad, pr.grad) for (k, pr), pm in zip(ref.named_parameters(), mine.parameters())}
+        _report("c2_training_step_vs_reference_formulation" + ("_fused_loss" if fused else ""), loss_rel=e_loss, logits=e_out,
+                logits_row_relative=e_out_rows, **errs)
+        assert e_loss < TOL and e_out < TOL and e_out_rows < TOL, (fused, e_loss, e_out, e_out_rows)
+        assert max(errs.values()) < TOL, (fused, errs)
+
+
 def test_golden_tiny_textgcn(cuda):
     z = np.load(os.path.join(GOLD, "tiny_textgcn.npz"))
     N = int(z["y"].shape[0])
