@@ -23,7 +23,9 @@ class GraphedTrainStep:
 
     The optimizer must be `pytextgcn_amd.optim.Adam(..., capturable=True)` (or any torch optimizer
     built with capturable=True).  `warmup` eager steps run first (they are real training steps); the
-    graph owns the gradient buffers afterwards, so do not call `zero_grad()` yourself.
+    graph owns the gradient buffers afterwards, so do not call `zero_grad()` yourself.  `mask` must not change
+    afterwards: its row count and the backward operator restricted to its rows (plan.transposed_on_rows, built during the
+    warm-up) are part of the captured step -- the masks of a TextGCN graph are static (text2graph.py:180-191).
     """
 
     def __init__(self, model, g, optimizer, mask: Tensor, warmup: int = 3):
