@@ -228,6 +228,12 @@ class GraphPlan:
             return None
         if keep.dtype != torch.bool or keep.device != self.device or keep.numel() != self.n_rows:
             raise ValueError(f"rows: a bool mask of {self.n_rows} entries on {self.device} is required")
+        builds = self.__dict__["_restricted_builds"] = self.__dict__.get("_restricted_builds", 0) + 1
+        if builds == 4:
+            import warnings
+            warnings.warn("pytextgcn_amd: `rows=` has been given four different mask tensors for one graph; every new tensor "
+                          "costs the construction of a restricted operator -- compute the mask once and pass the SAME "
+                          "tensor every call (e.g. rows_eval = g.val_mask | g.train_mask before the loop)")
         rowptr, col, val = self.export_csr()
         row = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), (rowptr[1:] - rowptr[:-1]).long())
         sel = keep[row]
