@@ -702,7 +702,7 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     return sorted(times)[len(times) // 2]
 
 
-def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False, narrow=False):
+def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False, narrow=False, rows=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
     summed with one all-reduce; predictions of the owned rows go to the host."""
@@ -716,6 +716,10 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
     train_l = sg.scatter_rows(is_doc & (u < 0.8))
     val_l = sg.scatter_rows(is_doc & (u >= 0.8) & (u < 0.9))
     del y_full, u
+    # rows: the caller names the rows it reads (training rows in the step, validation + training rows in evaluation); no
+    # hub row is among them, so the last propagate step loses one collective each way (ShardedGraph.rows_view)
+    rows_train = train_l if rows else None
+    rows_eval = (train_l | val_l) if rows else None
     pkg.enable_activation_reuse(reuse)
     # narrow: hub rows cross the links at the class width where the activation-free network allows (pytextgcn_amd/narrow.py)
     model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5, narrow_exchange=narrow).to(dev)
@@ -732,14 +736,14 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model.train()
-        loss = sharded_cross_entropy(sg, model(), y_l, train_l)
+        loss = sharded_cross_entropy(sg, model(rows=rows_train), y_l, train_l)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         model.sync_grads()
         opt.step()
         model.eval()
         with torch.no_grad():
-            logits = model()
+            logits = model(rows=rows_eval)
             _, pred = sharded_cross_entropy(sg, logits, y_l, val_l, return_pred=True)
             pred_val = pred[val_l].cpu().numpy()
             pred_train = pred[train_l].cpu().numpy()
@@ -1185,7 +1189,7 @@ def main():
                            lambda: distributed_parity(sg, g, N, F, x, gout, bias, dev, dist, headline_mode))
 
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
-    epoch_ms_narrow = epoch_ms_rows = None
+    epoch_ms_narrow = epoch_ms_rows = epoch_ms_narrow_rows = None
     diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
         if (world > 1 or force_sharded) else None
     if (world > 1 or force_sharded) and not args.no_epoch:
@@ -1200,6 +1204,13 @@ def main():
         if sg.rp > 0 and C % 4 == 0 and F % 4 == 0:
             epoch_ms_narrow = secondary("epoch_ms_fused_w1_reuse_narrow_exchange",
                                         lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True))
+        if sg.rp > 0:
+            epoch_ms_rows = secondary("epoch_ms_fused_w1_reuse_needed_rows_only",
+                                      lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, rows=True))
+            if C % 4 == 0 and F % 4 == 0:
+                epoch_ms_narrow_rows = secondary(
+                    "epoch_ms_fused_w1_reuse_narrow_exchange_needed_rows_only",
+                    lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True, rows=True))
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = secondary("epoch_ms", lambda: epoch_time_ms(g, F, C, fused=False))
@@ -1336,9 +1347,14 @@ def main():
             # N > 1, opt-in, fp32-equal (1e-5) but not bit-equal to the plain exchange: ShardedGCN(narrow_exchange=True) --
             # two of the four width-h collectives of a training step travel at the class width (pytextgcn_amd/narrow.py)
             "epoch_ms_fused_w1_reuse_narrow_exchange": epoch_ms_narrow,
+            # N > 1, opt-in: both at once -- `ShardedGCN.forward(rows=...)` on the narrow exchange
+            "epoch_ms_fused_w1_reuse_narrow_exchange_needed_rows_only": epoch_ms_narrow_rows,
             "exchange_floats_per_hub_row_and_step": None if parallelism == "single" else {
                 "plain": {"train": 4 * F + 4 * C, "eval": 2 * F + 2 * C},
                 "narrow": {"train": 2 * F + 6 * C, "eval": F + 3 * C},
+                # forward(rows=...): no hub row of the logits is read -- layer 2 loses one collective each way
+                "plain_needed_rows": {"train": 4 * F + 2 * C, "eval": 2 * F + C},
+                "narrow_needed_rows": {"train": 2 * F + 4 * C, "eval": F + 2 * C},
                 "hub_rows": int(sg.world * sg.hp), "bytes_per_float": 4,
                 "note": "each collective moves (W - 1) / W of the [W * hp] hub block per rank; an all-reduce counts as "
                         "reduce-scatter + all-gather; one epoch = one training step + one eval forward"},

@@ -25,6 +25,12 @@ all-reduce = RS + AG, all over the [W * hp] hub block):
             all-reduce of the small gradients sums.
 
 Two of the four width-h collectives become width-C ones: at c4 (h = 200, C = 64) 1056 -> 784 floats per hub row and step.
+When the caller names the rows it reads and none is a hub row (`ShardedGCN.forward(rows=...)`: the words of a TextGCN
+graph are never read, flat_amazon.py:101,109-114), layer 2 has no hub rows to produce and its gradient none to gather:
+
+    plain+rows forward  L1: AG(h) RS(h)     L2: AG(C)             backward  L2:       RS(C)     L1: AG(h) RS(h)     = 4 h + 2 C
+    narrow+rows forward L1: AG(h)  AR(C)    L2:                   backward  L2:       AR(C)     L1:       RS(h)     = 2 h + 4 C
+
 The sums associate differently over ranks than in the plain form, so the results agree with it to fp32 rounding (tests
 hold them to 1e-5), not bit for bit -- hence opt-in (`ShardedGCN(..., narrow_exchange=True)`).
 """
@@ -37,12 +43,19 @@ import torch.distributed as dist
 from torch import Tensor
 
 
-def exchange_floats_per_hub_row(h: int, C: int, narrow: bool, training: bool = True) -> int:
+def exchange_floats_per_hub_row(h: int, C: int, narrow: bool, training: bool = True, rows: bool = False,
+                                layer1_cached: bool = False) -> int:
     """Floats per hub row that one step puts through collectives (each AG / RS moves (W - 1) / W of the block per rank;
-    AR counts as RS + AG): the width-units of the module docstring."""
-    if training:
-        return 2 * h + 6 * C if narrow else 4 * h + 4 * C
-    return h + 3 * C if narrow else 2 * h + 2 * C
+    AR counts as RS + AG): the width-units of the module docstring.  `rows`: the caller names the rows it reads and none
+    is a hub row (`ShardedGCN.forward(rows=...)`): layer 2 loses its forward RS(C) and its backward AG(C).
+    `layer1_cached`: the forward pass finds layer 1's value from the preceding call (`enable_activation_reuse`)."""
+    l1_fwd = 0 if layer1_cached else (h if narrow else 2 * h)           # narrow: AG(h); plain: AG(h) RS(h)
+    l2_fwd = (2 * C if narrow else C) if rows else (3 * C if narrow else 2 * C)
+    if not training:
+        return l1_fwd + l2_fwd
+    l2_bwd = (2 * C if narrow else C) if rows else (3 * C if narrow else 2 * C)
+    l1_bwd = h if narrow else 2 * h
+    return l1_fwd + l2_fwd + l2_bwd + l1_bwd
 
 
 def _own(sg) -> slice:
@@ -79,10 +92,13 @@ class NarrowGCN2(torch.autograd.Function):
     """logits_local = the two-layer GCN of textgcn/lib/models.py:17-25 on one-hot features over the 1-D partition, with
     the exchange of the module docstring.  Inputs: the rank's W1 shard [n_local, h], b1, W2 [h, C], b2; `p` = dropout
     probability (0 in eval mode), `seed` = the group-common dropout seed (device int64[1]) or None; `cache` = None or a
-    dict the layer-1 partials are kept in between calls on unchanged (W1, b1) (`enable_activation_reuse`)."""
+    dict the layer-1 partials are kept in between calls on unchanged (W1, b1) (`enable_activation_reuse`); `view` = None
+    or the operators of the rows that are read (`ShardedGraph.rows_view`: no hub row among them) -- layer 2 then has no
+    hub rows to produce (its A_r and RS(C) go) and its gradient none to gather (the backward AG(C) goes): 2 h + 4 C."""
 
     @staticmethod
-    def forward(ctx, sg, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, p: float, seed: Optional[Tensor], cache):
+    def forward(ctx, sg, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, p: float, seed: Optional[Tensor], cache,
+                view=None):
         eng = sg.engine
         hp, rp, W = sg.hp, sg.rp, sg.world
         d = sg.dirs[0]
@@ -114,13 +130,14 @@ class NarrowGCN2(torch.autograd.Function):
             eng.gemm_nn(Yr, w2d, out=X2r)
         work = dist.all_reduce(Z, group=sg.group, async_op=True)      # -> XW2 of every hub row, on every rank
         # ---- layer 2: A_r on the own regular rows while the block is reduced; B_r reads the block as it is
-        pending = [sg._start_reduce(ch, ch.op.spmm(X2r)) for ch in d.chunks[sg.rs_chunks]]
+        pending = [] if view is not None else [sg._start_reduce(ch, ch.op.spmm(X2r)) for ch in d.chunks[sg.rs_chunks]]
         work.wait()
-        out = d.B.spmm(buf, b2d) if narrow_w else d.B.spmm(Z, b2d, x2=X2r)
+        B = d.B if view is None else view.B_rows
+        out = B.spmm(buf, b2d) if narrow_w else B.spmm(Z, b2d, x2=X2r)
         for finish in pending:
             finish(out[:hp])
         if want_grad:
-            ctx.sg, ctx.p, ctx.drop = sg, p, drop
+            ctx.sg, ctx.p, ctx.drop, ctx.view = sg, p, drop, view
             ctx.masks = (mP is not None, mR is not None)
             ctx.fused_param = w1 if isinstance(w1, torch.nn.Parameter) else None
             ctx.save_for_backward(P, Yr, w2d, *([seed] if drop else []), *[m for m in (mP, mR) if m is not None])
@@ -143,14 +160,21 @@ class NarrowGCN2(torch.autograd.Function):
         d_b2 = sg.colsum_real(g) if ctx.needs_input_grad[4] else None
         dT = sg.dirs[1 if not sg.symmetric else 0]
         # ---- layer 2 backward: G = M^T dOut; the hub rows are ALL-REDUCED (every rank gets every hub's row)
-        xbuf, gathered = sg._start_gather(dT, g)                       # AG at width C
-        PT = dT.A.spmm(g[hp:])                                        # [W * hp, C] partial sums
-        whole = sg._whole_operand(dT, g)
-        gathered()
-        Yb = sg._apply_B(dT, g, None, xbuf, whole)
-        PT[_own(sg)] += Yb[:hp]
+        view = ctx.view
+        if view is None:
+            xbuf, gathered = sg._start_gather(dT, g)                   # AG at width C
+            PT = dT.A.spmm(g[hp:])                                    # [W * hp, C] partial sums
+            whole = sg._whole_operand(dT, g)
+            gathered()
+            Yb = sg._apply_B(dT, g, None, xbuf, whole)
+            PT[_own(sg)] += Yb[:hp]
+            G_reg = Yb[hp:]
+        else:
+            # no hub row was read: the hub rows of g are zero on every rank -- nothing to gather, and B'_r's hub rows (hub
+            # columns only) contribute nothing
+            PT = view.At.spmm(g[hp:])
+            G_reg = view.Bt_reg.spmm(g[hp:])
         work = dist.all_reduce(PT, group=sg.group, async_op=True)
-        G_reg = Yb[hp:]
         # ---- the regular rows' share while the block is reduced; layer 1's partial sums and their reduce-scatter (the one
         # width-h collective left in the backward pass) start as early as their operand exists
         dH1_reg = eng.gemm_nt(G_reg, w2, p, seed, mask=mR, keys=kreg)          # [rp, h]; leaves its column sums
@@ -179,4 +203,4 @@ class NarrowGCN2(torch.autograd.Function):
         else:
             for finish in pending:                                    # the collective was entered: complete it on every rank
                 finish(torch.empty(hp, dH1_reg.size(1), dtype=dH1_reg.dtype, device=dH1_reg.device))
-        return None, d_w1, d_b1, d_w2, d_b2, None, None, None
+        return None, d_w1, d_b1, d_w2, d_b2, None, None, None, None

@@ -371,6 +371,47 @@ class _Direction:
         return ch[0].op if ch else None
 
 
+class _RowsView:
+    """The local operators restricted to the regular rows a mask keeps (ShardedGraph.rows_view): `B_rows` = B_r with the
+    other rows emptied (same operand as B_r), `At` / `At_chunks` = A'_r with the other COLUMNS dropped (same operand and
+    row chunks as A'_r, so the reduce lists of the chunks serve unchanged: a row that lost its entries travels as
+    zeros), `Bt_reg` [rp x rp] = the regular rows of B'_r over the kept regular columns.  Cut from the operators' own CSR:
+    same entries, same order within a row."""
+
+    def __init__(self, sg: "ShardedGraph", keep: Tensor):
+        hp, rp, W = sg.hp, sg.rp, sg.world
+        eng = sg.engine
+        d, dT = sg.dirs[0], sg.dirs[0 if sg.symmetric else 1]
+
+        def cut(op, n_rows, row_keep=None, col_keep=None, col0=0, row0=0, n_rows_out=None, n_cols_out=None):
+            rowptr, col, val = op.export_csr()
+            counts = (rowptr[1:] - rowptr[:-1]).long()
+            row = torch.repeat_interleave(torch.arange(n_rows, device=col.device), counts)
+            col = col.long()
+            sel = torch.ones_like(col, dtype=torch.bool)
+            if row_keep is not None:
+                sel &= (row >= row0) & row_keep[(row - row0).clamp_min(0)]
+            if col_keep is not None:
+                sel &= (col >= col0) & col_keep[(col - col0).clamp_min(0)]
+            return eng.make_op(row[sel] - (row0 if n_rows_out is not None else 0), col[sel] - (col0 if n_cols_out is not None else 0),
+                               val[sel], n_rows_out if n_rows_out is not None else n_rows,
+                               n_cols_out if n_cols_out is not None else op.n_cols), int(sel.sum())
+
+        self.keep = keep
+        self.B_rows, kept_b = cut(d.B, hp + rp, row_keep=keep, row0=hp)
+        at, kept_a = cut(dT.A, W * hp, col_keep=keep)
+        self.At = at
+        self.At_chunks = []
+        for ch in dT.chunks[sg.rs_chunks]:
+            c = _Chunk(at if sg.rs_chunks == 1 else cut(ch.op, W * ch.ck, col_keep=keep)[0], ch.k, ch.ck, ch.n_own)
+            for name in ("touch_rows", "touch_counts", "recv_counts", "recv_pos", "inv_halo", "inv_dense"):
+                setattr(c, name, getattr(ch, name))
+            self.At_chunks.append(c)
+        self.Bt_reg, kept_bt = cut(dT.B, hp + rp, row_keep=torch.ones_like(keep), row0=hp, col_keep=keep, col0=W * hp,
+                                   n_rows_out=rp, n_cols_out=rp)
+        self.kept_entries = {"B": kept_b, "At": kept_a, "Bt_reg": kept_bt}
+
+
 class ShardedGraph:
     _CHUNK = 1 << 23      # edges per pass of the local-operator construction (transients stay O(chunk))
     EXCHANGES = ("collective", "p2p", "halo")
@@ -1032,6 +1073,39 @@ class ShardedGraph:
         xbuf.copy_(recv)                                            # host -> device, synchronous
         return []
 
+    # ---- the rows somebody reads (ShardedGCN.forward(rows=...)) ------------------------------------------------------
+    def rows_view(self, rows: Tensor) -> Optional["_RowsView"]:
+        """The local operators of a LAST propagate step whose result is read on `rows` only (a bool mask over this rank's
+        n_local rows): None unless NO rank reads a hub row -- in a TextGCN graph the hubs are the words and the rows
+        read are documents (flat_amazon.py:101,109-114), so the hub rows of the result need not exist at all:
+
+            forward   y[rows] = B_r[rows, :] @ [gathered hubs ; own rows]      A_r and its reduce-scatter disappear;
+            backward  g is zero outside `rows`, so its hub rows are:           nothing to gather;
+                      d x[hubs] = RS(A'_r[:, rows] @ g_reg),  d x[regular] = B'_r[regular, rows] @ g_reg.
+
+        One collective of each propagate step and the entries of the unread rows go.  Built once per mask (kept with the
+        tensor, so its id cannot be recycled) and per chunk count.  COLLECTIVE on first use of a mask: the ranks agree
+        on whether any hub row is read (one all-reduce of a flag), so every rank must pass a mask in the same call or
+        none may."""
+        cache = self.__dict__.setdefault("_rows_views", {})
+        hit = cache.get(id(rows))
+        if hit is not None and hit[0] is rows and hit[1] == rows._version and hit[2] == self.rs_chunks:
+            return hit[3]
+        if rows.dtype != torch.bool or rows.dim() != 1 or rows.numel() != self.n_local:
+            raise ValueError(f"rows must be a bool mask over this rank's {self.n_local} rows")
+        if rows.device != self.real.device:
+            raise ValueError("rows must live where the graph does")
+        hp = self.hp
+        no = torch.zeros(1, dtype=torch.float32, device=self._comm_device())
+        if self.rp == 0 or bool((rows[:hp] & self.real[:hp]).any()):
+            no += 1.0
+        dist.all_reduce(no, op=dist.ReduceOp.MAX, group=self.group)
+        view = None if float(no.item()) > 0.0 else _RowsView(self, rows[hp:] & self.real[hp:])
+        if len(cache) >= 8:
+            cache.clear()
+        cache[id(rows)] = (rows, rows._version, self.rs_chunks, view)
+        return view
+
     def exchange_rows(self) -> dict:
         """Rows per SpMM this rank receives in each form (what the halo lists prune), for reports."""
         d = self.dirs[0]
@@ -1117,6 +1191,42 @@ def sharded_propagate(sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor]
     return _ShardedPropagate.apply(sg, xw_local, bias)
 
 
+class _ShardedPropagateRows(torch.autograd.Function):
+    """The last propagate step when only `view`'s rows of the result are read and none of them is a hub row
+    (ShardedGraph.rows_view): forward = all-gather + B_r's kept rows (every other row of the result holds the bias),
+    backward = A'_r on the kept rows + its reduce-scatter -- one collective each way instead of two."""
+
+    @staticmethod
+    def forward(ctx, sg: ShardedGraph, xw_local: Tensor, bias: Optional[Tensor], view: _RowsView):
+        ctx.sg, ctx.view = sg, view
+        ctx.has_bias = bias is not None
+        d = sg.dirs[0]
+        x = xw_local.detach().contiguous()
+        if x.shape[0] != sg.n_local:
+            raise ValueError(f"operand has {x.shape[0]} rows, this rank owns {sg.n_local}")
+        b = None if bias is None else bias.detach()
+        xbuf, gathered = sg._start_gather(d, x)
+        whole = sg._whole_operand(d, x)
+        gathered()
+        if whole is not None:
+            return view.B_rows.spmm(whole, b)
+        return view.B_rows.spmm(xbuf, b, x2=x[sg.hp:])
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        sg, view = ctx.sg, ctx.view
+        g = grad_out.contiguous()
+        d_xw = None
+        if ctx.needs_input_grad[1]:
+            gr = g[sg.hp:]                                     # rows nobody read carry no gradient: the hub rows are zero
+            pending = [sg._start_reduce(ch, ch.op.spmm(gr)) for ch in view.At_chunks]
+            d_xw = torch.cat([torch.zeros(sg.hp, g.size(1), dtype=g.dtype, device=g.device), view.Bt_reg.spmm(gr)])
+            for finish in pending:
+                finish(d_xw[:sg.hp])
+        d_bias = sg.colsum_real(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return None, d_xw, d_bias, None
+
+
 class ShardedGCN(nn.Module):
     """The GCN of textgcn/lib/models.py:6-25 for one-hot features (text2graph.py:179: X = I, so
     X @ W1 = W1), with W1 row-sharded like the graph: `layers_w[0]` is [n_local, hidden].  The
@@ -1181,10 +1291,15 @@ class ShardedGCN(nn.Module):
         self._seed_calls += 1
         return torch.full((1,), _wrap64(self._seed_base + self._seed_calls * 0x9E3779B97F4A7C15), dtype=torch.int64, device=dev)
 
-    def forward(self, g=None) -> Tensor:
-        """Logits of this rank's rows, [n_local, out_channels] (padding rows hold the bias)."""
+    def forward(self, g=None, rows: Optional[Tensor] = None) -> Tensor:
+        """Logits of this rank's rows, [n_local, out_channels] (padding rows hold the bias).
+        `rows` (as in `GCN.forward`; a bool mask over the rank's n_local rows that the caller keeps): the rows of the
+        result that will be READ.  When no rank reads a hub row (`ShardedGraph.rows_view`; the words of a TextGCN graph)
+        the last propagate step runs without A_r and its reduce-scatter, its backward without the all-gather, and every
+        row outside `rows` holds the last bias.  Every rank passes a mask in the same call, or none does."""
         eng = self.sg.engine
         fused_drop = self.training and 0.0 < self.dropout < 1.0
+        view = self.sg.rows_view(rows) if (rows is not None and len(self.weights) > 1) else None
         if self.narrow_exchange:
             from . import conv
             from .narrow import NarrowGCN2
@@ -1193,8 +1308,9 @@ class ShardedGCN(nn.Module):
                 raise ValueError("narrow_exchange: dropout must be < 1")
             cache = self.__dict__.setdefault("_narrow_cache", {}) if conv._REUSE else None
             return NarrowGCN2.apply(self.sg, self.weights[0], self.biases[0], self.weights[1], self.biases[1],
-                                    float(self.dropout) if fused_drop else 0.0, seed, cache)
+                                    float(self.dropout) if fused_drop else 0.0, seed, cache, view)
         x = self._layer1()
+        last = len(self.weights) - 1
         for i in range(1, len(self.weights)):
             if fused_drop and self.keyed_dropout and hasattr(eng, "xw_dropout_keyed"):
                 from .narrow import own_row_keys
@@ -1204,7 +1320,10 @@ class ShardedGCN(nn.Module):
             else:
                 x = nn.functional.dropout(x, p=self.dropout, training=self.training)
                 xw = eng.xw(x, self.weights[i])
-            x = sharded_propagate(self.sg, xw, self.biases[i])
+            if view is not None and i == last:
+                x = _ShardedPropagateRows.apply(self.sg, xw, self.biases[i], view)
+            else:
+                x = sharded_propagate(self.sg, xw, self.biases[i])
         return x
 
     def _layer1(self) -> Tensor:

@@ -21,6 +21,9 @@ class _OracleOp:
         self.n_rows, self.n_cols = n_rows, n_cols
         self.csr = csr_oracle.coo_to_csr(row, col, val, n_rows)
 
+    def export_csr(self):
+        return self.csr
+
     def spmm(self, x, bias=None, x2=None):
         if x2 is not None:
             x = torch.cat([x, x2])
@@ -162,6 +165,8 @@ def check(kind, device="cpu"):
     check_offline_construction(sg, g, hubs, N)
     if sg.rp > 0:
         check_narrow_exchange(sg, g, N)
+        for narrow in (False, True):
+            check_rows_option(sg, g, N, narrow=narrow)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
     torch.manual_seed(3)
@@ -236,6 +241,107 @@ def check(kind, device="cpu"):
     finally:
         pkg.enable_activation_reuse(False)
         sg.spmm = real_spmm
+
+
+def check_rows_option(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, narrow=False, fuse_w1=False, steps=2):
+    """ShardedGCN.forward(rows=mask) against the same model without the option, same exchange form, weights and keyed masks:
+    the logits of the rows that are read, the loss and every gradient at 1e-5 (the restricted operators are plans of
+    their own: same entries, possibly another order of summation); the unread rows hold the last bias; the collectives
+    that must have gone are counted; a mask that reads a hub row falls back to the whole operators (bit for bit)."""
+    import pytextgcn_amd as pkg
+    from pytextgcn_amd.narrow import exchange_floats_per_hub_row
+    dev = dev if dev is not None else torch.device("cpu")
+    torch.manual_seed(22)
+    init = O.GCNOracle(N, classes, n_hidden_gcn=hidden, dropout=0.0).state_dict()
+    y_l, m_l = sg.scatter_rows(g.y.to(dev) % classes), sg.scatter_rows(g.train_mask.to(dev))
+    assert not bool(m_l[:sg.hp].any())                       # the training rows are documents
+    names = ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor")
+    real = {k: getattr(dist, k) for k in names}
+
+    def counting(calls):
+        def wrap(name):
+            def f(*a, **kw):
+                calls[name] += 1
+                return real[name](*a, **kw)
+            return f
+        for k in names:
+            setattr(dist, k, wrap(k))
+    models, opts = [], []
+    for _ in range(2):
+        m = sharded.ShardedGCN(sg, N, classes, n_hidden_gcn=hidden, dropout=dropout, narrow_exchange=narrow,
+                               keyed_dropout=True).to(dev)
+        m.load_full_state_dict(init)
+        m._seed_base = 7654321
+        if dev.type == "cpu":
+            o = torch.optim.Adam(m.parameters(), lr=0.02, amsgrad=True)
+        else:
+            o = pkg.optim.Adam(m.parameters(), lr=0.02, amsgrad=True)
+            if fuse_w1:
+                o.fuse_into_backward(m.weights[0])
+        models.append(m), opts.append(o)
+    view = sg.rows_view(m_l)                                 # (collective; also what forward(rows=m_l) will find)
+    sharded.sharded_cross_entropy(sg, torch.zeros(sg.n_local, classes, device=dev), y_l, m_l)   # (the mask's row count: one all-reduce, once)
+    assert view is not None and view.kept_entries["B"] < sg.dirs[0].B.export_csr()[1].numel()
+    for step in range(steps):
+        outs = []
+        for m, o, rows in zip(models, opts, (None, m_l)):
+            m.train()
+            calls = {k: 0 for k in names}
+            if sg.exchange == "collective":
+                counting(calls)
+            try:
+                lo = m(rows=rows)
+                loss = sharded.sharded_cross_entropy(sg, lo, y_l, m_l)
+                o.zero_grad(set_to_none=True)
+                loss.backward()
+            finally:
+                for k in names:
+                    setattr(dist, k, real[k])
+            if sg.exchange == "collective":
+                K = sg.rs_chunks
+                if narrow:     # forward AG(h) AR(C) [RS(C)] | backward [AG(C)] AR(C) RS(h)
+                    want = {"all_reduce": 2, "all_gather_into_tensor": 2 if rows is None else 1,
+                            "reduce_scatter_tensor": (2 if rows is None else 1) * K}
+                else:          # forward AG RS | AG [RS]; backward [AG] RS | AG RS
+                    want = {"all_reduce": 0, "all_gather_into_tensor": 4 if rows is None else 3,
+                            "reduce_scatter_tensor": (4 if rows is None else 3) * K}
+                assert calls == want, (narrow, rows is not None, calls, want)
+            m.sync_grads()
+            grads = [None if p.grad is None else p.grad.detach().clone() for p in m.parameters()]
+            outs.append((loss.detach().clone(), lo.detach().clone(), grads))
+            o.step()
+        (l0, z0, g0), (l1, z1, g1) = outs
+        assert abs(l0.item() - l1.item()) <= 1e-5 * abs(l0.item()) + 1e-9, (step, l0, l1)
+        read = m_l.cpu()
+        assert rel_err(z1.cpu()[read], z0.cpu()[read]) < 1e-5, (step, rel_err(z1.cpu()[read], z0.cpu()[read]))
+        for a, b in zip(g0, g1):
+            assert (a is None) == (b is None)
+            if a is not None and a.numel() and float(a.abs().max()) > 0:
+                assert rel_err(b.cpu(), a.cpu()) < 1e-5, (step, tuple(a.shape), rel_err(b.cpu(), a.cpu()))
+    # evaluation: rows = everything evaluation reads (here: all documents); unread rows hold the bias
+    for m in models:
+        m.eval()
+    docs = sg.real.clone()
+    docs[:sg.hp] = False
+    with torch.no_grad():
+        full, part = models[1](), models[1](rows=docs)
+    assert rel_err(part.cpu()[docs.cpu()], full.cpu()[docs.cpu()]) < 1e-5
+    unread = ~docs.cpu()
+    assert torch.equal(part.cpu()[unread], models[1].biases[-1].detach().cpu().expand(int(unread.sum()), -1))
+    # a mask that reads a hub row on ONE rank: every rank falls back to the whole operators
+    hubby = docs.clone()
+    if dist.get_rank() == dist.get_world_size() - 1:
+        hubby[0] = bool(sg.real[0])
+    with torch.no_grad():
+        assert torch.equal(models[1](rows=hubby), full) and sg.rows_view(hubby) is None
+    try:
+        sg.rows_view(docs[:-1])
+        raise AssertionError("a mask of the wrong length was accepted")
+    except ValueError:
+        pass
+    h, C = 200, 64
+    assert exchange_floats_per_hub_row(h, C, False, rows=True) == 928 and exchange_floats_per_hub_row(h, C, True, rows=True) == 656
+    assert exchange_floats_per_hub_row(h, C, False, training=False, rows=True, layer1_cached=True) == C
 
 
 def check_narrow_exchange(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, steps=3, fuse_w1=False):
@@ -421,6 +527,9 @@ def check_hip(kind, g, hubs, N, dev):
         # update inside the backward SpMM
         check_narrow_exchange(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8)
         check_narrow_exchange(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, fuse_w1=True)
+        # forward(rows=...): the last propagate step on the rows that are read, both exchanges
+        check_rows_option(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, narrow=False)
+        check_rows_option(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, narrow=True, fuse_w1=True)
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
