@@ -167,6 +167,12 @@ def check(kind, device="cpu"):
         check_narrow_exchange(sg, g, N)
         for narrow in (False, True):
             check_rows_option(sg, g, N, narrow=narrow)
+        sg.set_rs_chunks(2)                                  # A'_r's kept columns cut per row chunk
+        try:
+            for narrow in (False, True):
+                check_rows_option(sg, g, N, narrow=narrow, steps=1)
+        finally:
+            sg.set_rs_chunks(1)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
     torch.manual_seed(3)
