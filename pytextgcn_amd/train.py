@@ -26,12 +26,15 @@ class GraphedTrainStep:
     graph owns the gradient buffers afterwards, so do not call `zero_grad()` yourself.  `mask` must not change
     afterwards: its row count and the backward operator restricted to its rows (plan.transposed_on_rows, built during the
     warm-up) are part of the captured step -- the masks of a TextGCN graph are static (text2graph.py:180-191).
+    `needed_rows_only`: the step reads the logits of the mask's rows only (flat_amazon.py:101), so the last layer computes
+    only those (`GCN.forward(g, rows=mask)`; the restricted operator is built during the warm-up as well).
     """
 
-    def __init__(self, model, g, optimizer, mask: Tensor, warmup: int = 3):
+    def __init__(self, model, g, optimizer, mask: Tensor, warmup: int = 3, needed_rows_only: bool = False):
         if not any(gr.get("capturable", False) for gr in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True")
         self.model, self.g, self.opt, self.mask = model, g, optimizer, mask
+        self._kw = {"rows": mask} if needed_rows_only else {}
         conv.enable_activation_reuse(False)          # a replay must not depend on Python-side caches
         _mask_count(mask)                            # the one host sync of the loss, done up front
         model.train()
@@ -44,13 +47,13 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.loss = masked_cross_entropy(model(g), g.y, mask)
+            self.loss = masked_cross_entropy(model(g, **self._kw), g.y, mask)
             self.loss.backward()
             optimizer.step()
         self.steps = max(1, warmup)                  # the capture itself does not execute the step
 
     def _eager_step(self):
-        loss = masked_cross_entropy(self.model(self.g), self.g.y, self.mask)
+        loss = masked_cross_entropy(self.model(self.g, **self._kw), self.g.y, self.mask)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         self.opt.step()
@@ -64,20 +67,23 @@ class GraphedTrainStep:
 
 
 class GraphedEval:
-    """`with no_grad: logits = model(g)` in eval mode as one graph replay; returns static logits."""
+    """`with no_grad: logits = model(g)` in eval mode as one graph replay; returns static logits.  `rows` (a bool mask
+    the caller keeps unchanged): the rows of the logits that will be read (`GCN.forward(g, rows=...)`: validation and
+    training rows, flat_amazon.py:109-114); every other row holds the last bias."""
 
-    def __init__(self, model, g):
+    def __init__(self, model, g, rows: Tensor = None):
         self.model, self.g = model, g
+        kw = {"rows": rows} if rows is not None else {}
         was_training = model.training
         model.eval()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            model(g)
+            model(g, **kw)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.logits = model(g)
+            self.logits = model(g, **kw)
         model.train(was_training)
 
     def __call__(self) -> Tensor:

@@ -1993,6 +1993,26 @@ def test_graphed_training_matches_eager_training(cuda):
     with torch.no_grad():
         assert rel_err(ev(), eager(g)) < 1e-4
     assert graphed.training                                       # GraphedEval restores the mode
+    # the same with only the rows that are read computed by the last layer: the captured step holds the restricted
+    # operators (built in the warm-up), the replay gives the eager loop's losses and weights
+    rows_m = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    torch.manual_seed(9)
+    fresh = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    rows_m.load_state_dict(fresh.state_dict())
+    o_r = pkg.optim.Adam(rows_m.parameters(), lr=0.05, amsgrad=True, capturable=True)
+    step_r = GraphedTrainStep(rows_m, g, o_r, g.train_mask, warmup=2, needed_rows_only=True)
+    losses_r = [step_r().item() for _ in range(4)]
+    for a, b in zip(losses_e[2:], losses_r):
+        assert abs(a - b) < 1e-5 * abs(a) + 1e-7
+    for pe, pr in zip(eager.parameters(), rows_m.parameters()):
+        assert rel_err(pr, pe) < 1e-4
+    read = g.val_mask | g.train_mask
+    ev_r = GraphedEval(rows_m, g, rows=read)
+    with torch.no_grad():
+        want = eager(g)
+    got = ev_r()
+    assert rel_err(got[read], want[read]) < 1e-4
+    assert torch.equal(got[~read], rows_m.layers[-1].bias.detach().expand(int((~read).sum()), -1))
 
 
 def test_three_layer_gcn_and_general_sparse_features(cuda):
