@@ -171,7 +171,11 @@ def check(kind, device="cpu"):
         try:
             for narrow in (False, True):
                 check_rows_option(sg, g, N, narrow=narrow, steps=1)
+            for form in ("p2p", "halo"):                     # the chunks' reduce lists serve the restricted operators
+                sg.exchange = form
+                check_rows_option(sg, g, N, narrow=False, steps=1)
         finally:
+            sg.exchange = "collective"
             sg.set_rs_chunks(1)
 
     # model level: ShardedGCN vs the oracle GCN, 3 Adam(amsgrad) steps, dropout off
