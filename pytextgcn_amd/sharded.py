@@ -1101,6 +1101,12 @@ class ShardedGraph:
             no += 1.0
         dist.all_reduce(no, op=dist.ReduceOp.MAX, group=self.group)
         view = None if float(no.item()) > 0.0 else _RowsView(self, rows[hp:] & self.real[hp:])
+        self._rows_views_built = getattr(self, "_rows_views_built", 0) + 1
+        if self._rows_views_built == 4:
+            import warnings
+            warnings.warn("ShardedGraph.rows_view: a fourth distinct `rows` mask -- the operators are built per mask TENSOR "
+                          "(one agreement among the ranks and three local operators each time); keep the masks and pass "
+                          "the same tensors every epoch", stacklevel=3)
         if len(cache) >= 8:
             cache.clear()
         cache[id(rows)] = (rows, rows._version, self.rs_chunks, view)
