@@ -33,6 +33,9 @@ p.add_argument("--hidden", type=int, default=100, help="hidden width (flat_amazo
 p.add_argument("--narrow", action="store_true",
                help="ShardedGCN(narrow_exchange=True): hub rows cross the links at the class width where the activation-free "
                     "network allows (pytextgcn_amd/narrow.py); needs hidden and class widths that are multiples of 4")
+p.add_argument("--rows", action="store_true",
+               help="gcn(rows=mask): name the rows of the logits the loop reads (documents only), so the last propagate step "
+                    "drops the word rows -- and one collective each way (ShardedGraph.rows_view)")
 p.add_argument("--fuse-w1", action="store_true",
                help="update this rank's W1 rows inside the backward SpMM (optim.Adam.fuse_into_backward; takes hidden > 128)")
 args = p.parse_args()
@@ -84,18 +87,21 @@ def accuracy(logits, mask):
     return (hit[0] / hit[1]).item()
 
 
+# --rows: kept tensors (the restricted operators are cached under them); every rank passes a mask in the same call
+rows_train = train_l if args.rows else None
+rows_eval = (train_l | val_l) if args.rows else None
 th.cuda.synchronize()
 t0 = time.time()
 for epoch in range(args.epochs):
     gcn.train()
-    loss = sharded_cross_entropy(sg, gcn(), y_l, train_l)
+    loss = sharded_cross_entropy(sg, gcn(rows=rows_train), y_l, train_l)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     gcn.sync_grads()
     optimizer.step()
     gcn.eval()
     with th.no_grad():
-        logits = gcn()
+        logits = gcn(rows=rows_eval)
         acc_val = accuracy(logits, val_l)
     total = loss.detach().clone()
     dist.all_reduce(total)
