@@ -28,6 +28,7 @@ Local layout on every rank: rows [0, hp) = own hub shard, rows [hp, hp + rp) = o
 """
 from __future__ import annotations
 
+import math
 from typing import List, Optional, Tuple
 
 import torch
@@ -1233,6 +1234,21 @@ class _ShardedPropagateRows(torch.autograd.Function):
         return None, d_xw, d_bias, None
 
 
+class _LocalFeatureBlock(torch.autograd.Function):
+    """H_local @ w and d w = H_local^T @ d out for this rank's rows of the hierarchy block H of [I | H]
+    (text2graph.py:237-241): two local operators, no exchange -- the sum of the ranks' d w is taken with the other small
+    gradients (`ShardedGCN.sync_grads`)."""
+
+    @staticmethod
+    def forward(ctx, op, op_t, w: Tensor):
+        ctx.op_t = op_t
+        return op.spmm(w.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        return None, None, ctx.op_t.spmm(grad_out.contiguous())
+
+
 class ShardedGCN(nn.Module):
     """The GCN of textgcn/lib/models.py:6-25 for one-hot features (text2graph.py:179: X = I, so
     X @ W1 = W1), with W1 row-sharded like the graph: `layers_w[0]` is [n_local, hidden].  The
@@ -1240,16 +1256,29 @@ class ShardedGCN(nn.Module):
     over ranks after backward (W1's gradient rows are owned and need no reduction)."""
 
     def __init__(self, sg: ShardedGraph, in_channels, out_channels, n_gcn=2, n_hidden_gcn=64,
-                 activation=nn.ReLU, dropout=0.5, narrow_exchange: bool = False, keyed_dropout: Optional[bool] = None):
-        """`narrow_exchange` (opt-in; two layers, a hub partition, widths that are multiples of 4): hub rows cross the
+                 activation=nn.ReLU, dropout=0.5, narrow_exchange: bool = False, keyed_dropout: Optional[bool] = None,
+                 hierarchy_feats: Optional[Tensor] = None):
+        """`hierarchy_feats`: this rank's rows [n_local, F_h] (local order: `sg.scatter_rows(H)`; dense or sparse COO) of the
+        hierarchy block H of the features [I_N | H] (text2graph.py:237-241; perlevel_amazon.py:122,156); then
+        `in_channels == num_nodes + F_h`, X @ W1 = W1[:N] + H @ W1[N:], the rows W1[N:] are a small replicated parameter
+        (`weight_h`) whose gradient H^T dXW is summed over the ranks with the other small gradients.
+        `narrow_exchange` (opt-in; two layers, a hub partition, widths that are multiples of 4): hub rows cross the
         links at the class width wherever the activation-free network allows it -- pytextgcn_amd/narrow.py; fp32-equal to
         the plain exchange (1e-5), not bit-equal.  `keyed_dropout`: the fused dropout's mask is a function of a node's
         position in the PARTITION and of a seed common to the group (so any rank can evaluate a hub row's mask) instead of
         the local row and a per-rank seed; implied by `narrow_exchange`, available on its own so that the two exchanges
         can be run on identical masks."""
         super().__init__()
-        if in_channels != sg.num_nodes:
-            raise ValueError("ShardedGCN implements the one-hot feature case: in_channels must equal num_nodes")
+        F_h = 0
+        if hierarchy_feats is not None:
+            if hierarchy_feats.dim() != 2 or hierarchy_feats.size(0) != sg.n_local:
+                raise ValueError(f"hierarchy_feats must hold this rank's {sg.n_local} rows (sg.scatter_rows of the block)")
+            F_h = int(hierarchy_feats.size(1))
+        if in_channels != sg.num_nodes + F_h:
+            raise ValueError("ShardedGCN implements one-hot features, alone or followed by a hierarchy block [I | H]: "
+                             "in_channels must equal num_nodes (+ the block's width)")
+        if F_h and narrow_exchange:
+            raise ValueError("narrow_exchange serves the one-hot features alone")
         self.narrow_exchange = bool(narrow_exchange)
         self.keyed_dropout = self.narrow_exchange if keyed_dropout is None else bool(keyed_dropout)
         if self.narrow_exchange:
@@ -1269,19 +1298,45 @@ class ShardedGCN(nn.Module):
             self.weights.append(nn.Parameter(glorot_(torch.empty(dims[i - 1], dims[i]))))
             self.biases.append(nn.Parameter(torch.zeros(dims[i])))
         self.in_channels = in_channels
+        self.weight_h = None
+        self._h_ops = None
+        if F_h:
+            # the rows W1[N:] of the reference's (N + F_h) x h weight: replicated, glorot bound of the whole matrix
+            bound = math.sqrt(6.0 / (in_channels + dims[0]))
+            self.weight_h = nn.Parameter(torch.empty(F_h, dims[0]).uniform_(-bound, bound))
+            hf = hierarchy_feats
+            if hf.is_sparse:
+                hf = hf.coalesce()
+                (r, c), v = hf.indices(), hf.values().float()
+            else:
+                r, c = torch.nonzero(hf, as_tuple=True)
+                v = hf[r, c].float()
+            keep = sg.real.to(r.device)[r]                       # padding rows own nothing
+            r, c, v = r[keep], c[keep], v[keep]
+            self._h_ops = (sg.engine.make_op(r, c, v, sg.n_local, F_h), sg.engine.make_op(c, r, v, F_h, sg.n_local))
 
     def load_full_state_dict(self, sd: dict) -> None:
         """From a single-device GCN state_dict (`layers.{i}.weight` / `.bias`, PyG-1.6.3 layout)."""
+        N = self.sg.num_nodes
         with torch.no_grad():
             for i, (w, b) in enumerate(zip(self.weights, self.biases)):
                 fw = sd[f"layers.{i}.weight"].to(w.device)
-                w.copy_(self.sg.scatter_rows(fw) if i == 0 else fw)
+                if i == 0:
+                    w.copy_(self.sg.scatter_rows(fw[:N]))
+                    if self.weight_h is not None:
+                        self.weight_h.copy_(fw[N:])
+                else:
+                    w.copy_(fw)
                 b.copy_(sd[f"layers.{i}.bias"].to(b.device))
 
     def full_state_dict(self) -> dict:
         sd = {}
         for i, (w, b) in enumerate(zip(self.weights, self.biases)):
-            sd[f"layers.{i}.weight"] = self.sg.gather_rows(w.detach()) if i == 0 else w.detach().clone()
+            if i == 0:
+                full = self.sg.gather_rows(w.detach())
+                sd["layers.0.weight"] = full if self.weight_h is None else torch.cat([full, self.weight_h.detach()])
+            else:
+                sd[f"layers.{i}.weight"] = w.detach().clone()
             sd[f"layers.{i}.bias"] = b.detach().clone()
         return sd
 
@@ -1340,6 +1395,10 @@ class ShardedGCN(nn.Module):
         version counters move in lock step), so the collectives stay matched."""
         from . import conv
         w, b = self.weights[0], self.biases[0]
+        if self.weight_h is not None:
+            # [I | H] features: X @ W1 = W1[:N] + H @ W1[N:] on this rank's rows; the operand is then a value, not the
+            # parameter (no optimizer inside the backward SpMM, no reuse across calls)
+            return sharded_propagate(self.sg, w + _LocalFeatureBlock.apply(self._h_ops[0], self._h_ops[1], self.weight_h), b)
         if not conv._REUSE:
             return sharded_propagate(self.sg, w, b)
         key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
@@ -1353,7 +1412,8 @@ class ShardedGCN(nn.Module):
         return out
 
     def sync_grads(self) -> None:
-        grads = [p.grad for p in list(self.weights)[1:] + list(self.biases) if p.grad is not None]
+        small = list(self.weights)[1:] + list(self.biases) + ([self.weight_h] if self.weight_h is not None else [])
+        grads = [p.grad for p in small if p.grad is not None]
         if grads:
             self.sg.allreduce_(grads)
 

@@ -167,6 +167,7 @@ def check(kind, device="cpu"):
         check_narrow_exchange(sg, g, N)
         for narrow in (False, True):
             check_rows_option(sg, g, N, narrow=narrow)
+        check_hierarchy_block(sg, g, N)
         sg.set_rs_chunks(2)                                  # A'_r's kept columns cut per row chunk
         try:
             for narrow in (False, True):
@@ -251,6 +252,70 @@ def check(kind, device="cpu"):
     finally:
         pkg.enable_activation_reuse(False)
         sg.spmm = real_spmm
+
+
+def check_hierarchy_block(sg, g, N, dev=None, hidden=16, classes=5, F_h=6):
+    """ShardedGCN with the features [I_N | H] of the hierarchical scripts (text2graph.py:237-241): against the oracle GCN on
+    the whole graph with the same sparse feature matrix -- loss, logits and every gradient (W1's identity rows gathered, the
+    replicated rows W1[N:] summed by sync_grads) over two Adam(amsgrad) steps; the state dict round trip."""
+    import copy
+    dev = dev if dev is not None else torch.device("cpu")
+    gen = torch.Generator().manual_seed(31)
+    H = torch.rand(N, F_h, generator=gen) * (torch.rand(N, F_h, generator=gen) < 0.4)
+    H[:int(getattr(g, "n_vocab", 0) or 0)] = 0                    # word rows carry no hierarchy features (:238-241)
+    ar = torch.arange(N)
+    hr, hc = torch.nonzero(H, as_tuple=True)
+    x = torch.sparse_coo_tensor(torch.stack([torch.cat([ar, hr]), torch.cat([ar, N + hc])]),
+                                torch.cat([torch.ones(N), H[hr, hc]]), (N, N + F_h)).coalesce()
+    g2 = copy.copy(g)
+    g2.x = x
+    torch.manual_seed(8)
+    ref = O.GCNOracle(N + F_h, classes, n_hidden_gcn=hidden, dropout=0.0)
+    H_l = sg.scatter_rows(H.to(dev))
+    for feats in (H_l, H_l.to_sparse()):
+        mine = sharded.ShardedGCN(sg, N + F_h, classes, n_hidden_gcn=hidden, dropout=0.0, hierarchy_feats=feats).to(dev)
+        mine.load_full_state_dict(ref.state_dict())
+        ref_i = copy.deepcopy(ref)
+        o_r = torch.optim.Adam(ref_i.parameters(), lr=0.05, amsgrad=True)
+        if dev.type == "cpu":
+            o_m = torch.optim.Adam(mine.parameters(), lr=0.05, amsgrad=True)
+        else:
+            import pytextgcn_amd as pkg
+            o_m = pkg.optim.Adam(mine.parameters(), lr=0.05, amsgrad=True)
+        y_l, m_l = sg.scatter_rows(g.y.to(dev) % classes), sg.scatter_rows(g.train_mask.to(dev))
+        crit = torch.nn.CrossEntropyLoss()
+        for step in range(2):
+            ref_i.train(), mine.train()
+            lo_r = ref_i(g2)
+            loss_r = crit(lo_r[g.train_mask], g.y[g.train_mask] % classes)
+            o_r.zero_grad(set_to_none=True)
+            loss_r.backward()
+            lo_m = mine()
+            loss_m = sharded.sharded_cross_entropy(sg, lo_m, y_l, m_l)
+            o_m.zero_grad(set_to_none=True)
+            loss_m.backward()
+            mine.sync_grads()
+            total = loss_m.detach().clone().reshape(1)
+            dist.all_reduce(total)
+            assert abs(total.item() - loss_r.item()) < 1e-5 * abs(loss_r.item()), (step, total, loss_r)
+            assert rel_err(sg.gather_rows(lo_m.detach()).cpu(), lo_r.detach()) < 1e-5, step
+            gw = ref_i.layers[0].weight.grad
+            assert rel_err(sg.gather_rows(mine.weights[0].grad).cpu(), gw[:N]) < 2e-5, step
+            assert rel_err(mine.weight_h.grad.cpu(), gw[N:]) < 2e-5, (step, rel_err(mine.weight_h.grad.cpu(), gw[N:]))
+            assert rel_err(mine.weights[1].grad.cpu(), ref_i.layers[1].weight.grad) < 2e-5
+            for i in (0, 1):
+                assert rel_err(mine.biases[i].grad.cpu(), ref_i.layers[i].bias.grad) < 2e-5
+            o_r.step(), o_m.step()
+        sd = mine.full_state_dict()
+        assert sd["layers.0.weight"].shape == (N + F_h, hidden)
+        for k, v in ref_i.state_dict().items():
+            assert rel_err(sd[k].cpu(), v) < 1e-3, k
+    for bad in (dict(hierarchy_feats=H_l[:-1]), dict(hierarchy_feats=H_l, narrow_exchange=True)):
+        try:
+            sharded.ShardedGCN(sg, N + F_h, classes if "narrow_exchange" not in bad else 8, n_hidden_gcn=hidden, **bad)
+            raise AssertionError(f"accepted {list(bad)}")
+        except ValueError:
+            pass
 
 
 def check_rows_option(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, narrow=False, fuse_w1=False, steps=2):
@@ -540,6 +605,8 @@ def check_hip(kind, g, hubs, N, dev):
         # forward(rows=...): the last propagate step on the rows that are read, both exchanges
         check_rows_option(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, narrow=False)
         check_rows_option(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, narrow=True, fuse_w1=True)
+        # the features [I | H] of the hierarchical scripts on the partition
+        check_hierarchy_block(sg, g, N, dev, hidden=F)
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
