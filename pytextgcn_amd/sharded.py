@@ -1315,6 +1315,24 @@ class ShardedGCN(nn.Module):
             r, c, v = r[keep], c[keep], v[keep]
             self._h_ops = (sg.engine.make_op(r, c, v, sg.n_local, F_h), sg.engine.make_op(c, r, v, F_h, sg.n_local))
 
+    @classmethod
+    def for_data(cls, sg: ShardedGraph, g, out_channels, **kw) -> "ShardedGCN":
+        """The model for the graph object Text2GraphTransformer returns (text2graph.py:192-193), built like the reference
+        builds its own (`model(g.x.shape[1], n_classes, ...)`, flat_amazon.py:80): `g.x` is the sparse identity, or
+        [I_N | H] with the hierarchy block (text2graph.py:226-246), whose rows are handed to this rank."""
+        from .conv import is_sparse_identity, split_identity_block
+        x, N = g.x, sg.num_nodes
+        if x.size(0) != N or not x.is_sparse:
+            raise ValueError("ShardedGCN serves the sparse one-hot features of text2graph.py:226-246 ([I_N] or [I_N | H])")
+        if x.size(1) == N:
+            if not is_sparse_identity(x):
+                raise ValueError("g.x is square but not the identity")
+            return cls(sg, N, out_channels, **kw)
+        H = split_identity_block(x)
+        if H is None:
+            raise ValueError("g.x is wider than it is tall but its first N columns are not the identity")
+        return cls(sg, x.size(1), out_channels, hierarchy_feats=sg.scatter_rows(H.to_dense()).to_sparse(), **kw)
+
     def load_full_state_dict(self, sd: dict) -> None:
         """From a single-device GCN state_dict (`layers.{i}.weight` / `.bias`, PyG-1.6.3 layout)."""
         N = self.sg.num_nodes

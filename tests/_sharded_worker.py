@@ -310,6 +310,18 @@ def check_hierarchy_block(sg, g, N, dev=None, hidden=16, classes=5, F_h=6):
         assert sd["layers.0.weight"].shape == (N + F_h, hidden)
         for k, v in ref_i.state_dict().items():
             assert rel_err(sd[k].cpu(), v) < 1e-3, k
+    # built from the graph object, as the reference builds its model from g.x.shape[1] (flat_amazon.py:80)
+    g2d = copy.copy(g2)
+    g2d.x = x.to(dev)
+    auto = sharded.ShardedGCN.for_data(sg, g2d, classes, n_hidden_gcn=hidden, dropout=0.0).to(dev)
+    auto.load_full_state_dict(ref.state_dict())
+    plain = copy.copy(g)
+    ar_d = torch.arange(N, device=dev)
+    plain.x = torch.sparse_coo_tensor(torch.stack([ar_d, ar_d]), torch.ones(N, device=dev), (N, N))
+    assert sharded.ShardedGCN.for_data(sg, plain, classes).weight_h is None
+    ref.eval(), auto.eval()
+    with torch.no_grad():
+        assert rel_err(sg.gather_rows(auto()).cpu(), ref(g2)) < 1e-5
     for bad in (dict(hierarchy_feats=H_l[:-1]), dict(hierarchy_feats=H_l, narrow_exchange=True)):
         try:
             sharded.ShardedGCN(sg, N + F_h, classes if "narrow_exchange" not in bad else 8, n_hidden_gcn=hidden, **bad)
