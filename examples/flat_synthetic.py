@@ -16,13 +16,13 @@ import torch as th
 from sklearn.metrics import accuracy_score, f1_score
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pytextgcn_amd import Text2GraphTransformer, functional, optim, synth  # noqa: E402
+from pytextgcn_amd import Text2GraphTransformer, synth  # noqa: E402
 from pytextgcn_amd.models import GCN  # noqa: E402
 
 p = argparse.ArgumentParser()
 p.add_argument("--docs", type=int, default=5000)
 p.add_argument("--epochs", type=int, default=50)
-p.add_argument("--fused", action="store_true", help="pytextgcn_amd.functional / optim instead of torch's CE / Adam")
+p.add_argument("--fused", action="store_true", help="pytextgcn_amd.train.FlatLoop: the same epoch with every switch of the package instead of torch's CE / Adam / dropout")
 args = p.parse_args()
 
 seed, lr, dropout, window_size, min_df = 44, 0.05, 0.7, 20, 5          # :22-35,66
@@ -42,32 +42,38 @@ criterion = th.nn.CrossEntropyLoss(reduction="mean")                   # :82
 device = th.device("cuda")                                             # :84
 gcn = gcn.to(device).float()                                           # :85
 g = g.to(device)                                                       # :86
-Opt = optim.Adam if args.fused else th.optim.Adam
-optimizer = Opt(gcn.parameters(), lr=lr, amsgrad=True)                 # :89
-
-rows_eval = g.val_mask | g.train_mask          # --fused: the last layer computes only the logits rows that are read (kept tensors:
-rows_train = g.train_mask                      # the restricted operators are cached under them)
+y_val, y_train = g.y.cpu()[g.val_mask.cpu()], g.y.cpu()[g.train_mask.cpu()]
 th.cuda.synchronize()
 t0 = time.time()
-for epoch in range(args.epochs):                                       # :99-117
-    gcn.train()
-    if args.fused:
-        loss = functional.masked_cross_entropy(gcn(g, rows=rows_train), g.y, g.train_mask)
-    else:
+if args.fused:
+    # the same epoch behind one object: fused loss / optimizer / dropout kernels, W1's update inside the backward SpMM, layer
+    # 1's activation kept from the evaluation pass, only the logits rows that are read, predictions (not logits) to the host
+    from pytextgcn_amd.train import FlatLoop
+    with FlatLoop(gcn, g, lr=lr) as loop:                              # :89 + :99-117
+        for epoch in range(args.epochs):
+            loss, _, pred_val, pred_train = loop.epoch()
+            f1_val = f1_score(y_val, pred_val, average="macro")
+            acc_train = accuracy_score(y_train, pred_train)
+            if epoch % 10 == 0 or epoch == args.epochs - 1:
+                print(f"[{epoch + 1:3d}] loss: {loss: .3f}, training accuracy: {acc_train: .3f}, val_f1: {f1_val: .3f}")
+else:
+    optimizer = th.optim.Adam(gcn.parameters(), lr=lr, amsgrad=True)   # :89
+    for epoch in range(args.epochs):                                   # :99-117
+        gcn.train()
         outputs = gcn(g)[g.train_mask]
         loss = criterion(outputs, g.y[g.train_mask])
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    optimizer.step()
-    gcn.eval()
-    with th.no_grad():
-        logits = gcn(g, rows=rows_eval) if args.fused else gcn(g)
-        pred_val = np.argmax(logits[g.val_mask].cpu().numpy(), axis=1)
-        pred_train = np.argmax(logits[g.train_mask].cpu().numpy(), axis=1)
-        f1_val = f1_score(g.y.cpu()[g.val_mask.cpu()], pred_val, average="macro")
-        acc_train = accuracy_score(g.y.cpu()[g.train_mask.cpu()], pred_train)
-    if epoch % 10 == 0 or epoch == args.epochs - 1:
-        print(f"[{epoch + 1:3d}] loss: {loss.item(): .3f}, training accuracy: {acc_train: .3f}, val_f1: {f1_val: .3f}")
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        gcn.eval()
+        with th.no_grad():
+            logits = gcn(g)
+            pred_val = np.argmax(logits[g.val_mask].cpu().numpy(), axis=1)
+            pred_train = np.argmax(logits[g.train_mask].cpu().numpy(), axis=1)
+            f1_val = f1_score(y_val, pred_val, average="macro")
+            acc_train = accuracy_score(y_train, pred_train)
+        if epoch % 10 == 0 or epoch == args.epochs - 1:
+            print(f"[{epoch + 1:3d}] loss: {loss.item(): .3f}, training accuracy: {acc_train: .3f}, val_f1: {f1_val: .3f}")
 th.cuda.synchronize()
 print(f"{args.epochs} epochs in {time.time() - t0:.2f} s")
 with th.no_grad():                                                     # :130-134

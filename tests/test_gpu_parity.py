@@ -2015,6 +2015,73 @@ def test_graphed_training_matches_eager_training(cuda):
     assert torch.equal(got[~read], rows_m.layers[-1].bias.detach().expand(int((~read).sum()), -1))
 
 
+def test_flat_loop_is_the_manual_loop_with_every_switch(cuda):
+    """pytextgcn_amd.train.FlatLoop against the loop body written out by hand with the same switches (bit for bit: losses,
+    predictions, weights), against the oracle's loop at dropout 0 (1e-5 on the losses, same predictions up to ties), and
+    the package-wide switches restored when it closes."""
+    from pytextgcn_amd import conv as conv_, models as models_
+    from pytextgcn_amd.functional import masked_cross_entropy
+    from pytextgcn_amd.train import FlatLoop
+    N, C = 6000, 7
+    g = synth.word_doc_graph(N, 90000, seed=29, n_classes=C, device=cuda)
+
+    def fresh(p):
+        torch.manual_seed(13)
+        return pkg.GCN(N, C, n_hidden_gcn=200, dropout=p).to(cuda)
+    for p in (0.5, 0.0):
+        a, b = fresh(p), fresh(p)
+        torch.manual_seed(77)
+        with FlatLoop(a, g, lr=0.05) as loop:
+            assert models_._FUSED_DROPOUT and conv_._REUSE
+            got = [loop.epoch() for _ in range(4)]
+            test_pred = loop.test()
+        assert not models_._FUSED_DROPOUT and not conv_._REUSE
+        assert loop.epochs == 4 and test_pred.shape == (int(g.test_mask.sum()),)
+        # the same by hand
+        torch.manual_seed(77)
+        pkg.enable_fused_dropout(True), pkg.enable_activation_reuse(True)
+        try:
+            opt = pkg.optim.Adam(b.parameters(), lr=0.05, amsgrad=True)
+            opt.fuse_into_backward(b.layers[0].weight)
+            rows_eval = g.val_mask | g.train_mask
+            want = []
+            for _ in range(4):
+                b.train()
+                loss = masked_cross_entropy(b(g, rows=g.train_mask), g.y, g.train_mask)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                b.eval()
+                with torch.no_grad():
+                    vl, pred = masked_cross_entropy(b(g, rows=rows_eval), g.y, g.val_mask, return_pred=True)
+                want.append((loss.item(), vl.item(), pred[g.val_mask].cpu().numpy(), pred[g.train_mask].cpu().numpy()))
+        finally:
+            pkg.enable_fused_dropout(False), pkg.enable_activation_reuse(False)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb)
+        for (l, v, _, _), (lw, vw, _, _) in zip(got, want):
+            assert l == lw and v == vw
+        assert (got[-1][2] == want[-1][2]).all() and (got[-1][3] == want[-1][3]).all()     # (the buffer of the LAST call)
+        if p == 0.0:
+            # the reference's loop on the oracle (flat_amazon.py:99-117), dropout off
+            torch.manual_seed(13)
+            ref = O.GCNOracle(N, C, n_hidden_gcn=200, dropout=0.0)
+            ref.load_state_dict({k: v.cpu() for k, v in fresh(0.0).state_dict().items()})
+            gc = g.to("cpu")
+            o_r = torch.optim.Adam(ref.parameters(), lr=0.05, amsgrad=True)
+            crit = torch.nn.CrossEntropyLoss()
+            for (l, v, _, _) in got:
+                ref.train()
+                lr_ = crit(ref(gc)[gc.train_mask], gc.y[gc.train_mask])
+                o_r.zero_grad(set_to_none=True)
+                lr_.backward()
+                o_r.step()
+                ref.eval()
+                with torch.no_grad():
+                    vr = crit(ref(gc)[gc.val_mask], gc.y[gc.val_mask])
+                assert abs(l - lr_.item()) < 2e-5 * abs(lr_.item()) and abs(v - vr.item()) < 2e-5 * abs(vr.item()), (l, lr_, v, vr)
+
+
 def test_three_layer_gcn_and_general_sparse_features(cuda):
     """n_gcn = 3 (input -> h -> h -> classes, models.py:11-15) and a sparse feature matrix that is NOT
     the identity: X @ W1 and its weight gradient run on the HIP SpMM over a rectangular feature plan
