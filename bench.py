@@ -702,6 +702,26 @@ def epoch_time_ms(g, F, n_classes, fused, reps=5, reuse=False, collapse=False, f
     return sorted(times)[len(times) // 2]
 
 
+def flat_loop_epoch_ms(g, F, n_classes, reps=5):
+    """The same epoch through the package's own loop object, `pytextgcn_amd.train.FlatLoop` (every switch that leaves the
+    numbers alone + only the rows that are read): what a user gets from three lines, timed like `epoch_time_ms`."""
+    import pytextgcn_amd as pkg
+    from pytextgcn_amd.train import FlatLoop
+    N = g.y.numel()
+    model = pkg.GCN(N, n_classes, n_hidden_gcn=F, dropout=0.5).to(g.y.device).float()
+    times = []
+    with FlatLoop(model, g, lr=0.05) as loop:
+        for rep in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop.epoch()
+            torch.cuda.synchronize()
+            if rep:
+                times.append((time.perf_counter() - t0) * 1e3)
+    del model, loop
+    return sorted(times)[len(times) // 2]
+
+
 def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False, narrow=False, rows=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
@@ -1189,7 +1209,7 @@ def main():
                            lambda: distributed_parity(sg, g, N, F, x, gout, bias, dev, dist, headline_mode))
 
     epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
-    epoch_ms_narrow = epoch_ms_rows = epoch_ms_narrow_rows = None
+    epoch_ms_narrow = epoch_ms_rows = epoch_ms_narrow_rows = epoch_ms_flat_loop = None
     diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
         if (world > 1 or force_sharded) else None
     if (world > 1 or force_sharded) and not args.no_epoch:
@@ -1224,6 +1244,7 @@ def main():
                                       lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True))
         epoch_ms_rows = secondary("epoch_ms_fused_w1_reuse_needed_rows_only",
                                   lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, needed_rows=True))
+        epoch_ms_flat_loop = secondary("epoch_ms_flat_loop", lambda: flat_loop_epoch_ms(g, F, C))
         epoch_ms_split = secondary("epoch_ms_fused_w1_reuse_split_bf16_gemms",
                                    lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))
 
@@ -1343,6 +1364,8 @@ def main():
             # logits rows that are consumed (training rows in the step; validation + training rows in evaluation); the word
             # rows, two thirds of the operator's entries, are read by nobody.  NOT part of the metric
             "epoch_ms_fused_w1_reuse_needed_rows_only": epoch_ms_rows,
+            # the same loop through the package's own object, pytextgcn_amd.train.FlatLoop(gcn, g, lr).epoch()
+            "epoch_ms_flat_loop": epoch_ms_flat_loop,
             "epoch_ms_fused_w1_reuse_split_bf16_gemms": epoch_ms_split,
             # N > 1, opt-in, fp32-equal (1e-5) but not bit-equal to the plain exchange: ShardedGCN(narrow_exchange=True) --
             # two of the four width-h collectives of a training step travel at the class width (pytextgcn_amd/narrow.py)
