@@ -1464,3 +1464,64 @@ def sharded_cross_entropy(sg: ShardedGraph, logits_local: Tensor, y_local: Tenso
     else:
         part = logits_local.sum() * 0.0
     return (part / cnt, logits_local.argmax(1)) if return_pred else part / cnt
+
+
+class FlatLoop:
+    """The epoch of flat_amazon.py:99-117 on the 1-D partition behind one object (the multi-GPU counterpart of
+    `pytextgcn_amd.train.FlatLoop`): training step (forward, cross-entropy over the GLOBAL training rows, backward, the small
+    gradients summed over the ranks, Adam(amsgrad)) + evaluation pass, with W1's update inside the backward SpMM, layer 1 kept
+    from the evaluation pass for the next training pass, and -- `needed_rows_only` -- the last propagate step on the rows
+    that are read (`ShardedGCN.forward(rows=...)`: one collective less each way when no rank reads a hub row).
+
+        loop = sharded.FlatLoop(model, y_local, train_local, val_local, lr=lr)
+        loss, val_loss, pred_val, pred_train = loop.epoch()       # global losses; class ids of THIS rank's rows (numpy)
+
+    Every rank calls `epoch()` together.  `optimizer`: None = `pytextgcn_amd.optim.Adam` (GPU); any torch optimizer over
+    `model.parameters()` otherwise.  `enable_activation_reuse` is ON while the loop lives (`close()` / `with`)."""
+
+    def __init__(self, model: ShardedGCN, y_local: Tensor, train_local: Tensor, val_local: Tensor, lr: float = 0.05,
+                 amsgrad: bool = True, weight_decay: float = 0.0, needed_rows_only: bool = True, optimizer=None):
+        from . import conv
+        self.model, self.sg = model, model.sg
+        self.y, self.train_mask, self.val_mask = y_local, train_local, val_local
+        if optimizer is None:
+            from .optim import Adam
+            optimizer = Adam(model.parameters(), lr=lr, amsgrad=amsgrad, weight_decay=weight_decay)
+        self.optimizer = optimizer
+        if hasattr(optimizer, "fuse_into_backward"):
+            optimizer.fuse_into_backward(model.weights[0])     # (declines by itself where it does not apply)
+        self._saved = conv._REUSE
+        conv.enable_activation_reuse(True)
+        self.rows_train = train_local if needed_rows_only else None
+        self.rows_eval = (train_local | val_local) if needed_rows_only else None
+        self.epochs = 0
+
+    def epoch(self):
+        model, sg, opt = self.model, self.sg, self.optimizer
+        model.train()
+        loss = sharded_cross_entropy(sg, model(rows=self.rows_train), self.y, self.train_mask)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        model.sync_grads()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            val_loss, pred = sharded_cross_entropy(sg, model(rows=self.rows_eval), self.y, self.val_mask, return_pred=True)
+            both = torch.stack([loss.detach(), val_loss.detach()]).float()      # this rank's shares of the two means
+            dist.all_reduce(both, group=sg.group)
+            pred_val, pred_train = pred[self.val_mask].cpu().numpy(), pred[self.train_mask].cpu().numpy()
+        self.epochs += 1
+        lo = both.tolist()
+        return lo[0], lo[1], pred_val, pred_train
+
+    def close(self) -> None:
+        if self._saved is not None:
+            from . import conv
+            conv.enable_activation_reuse(self._saved)
+            self._saved = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

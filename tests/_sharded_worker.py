@@ -168,6 +168,8 @@ def check(kind, device="cpu"):
         for narrow in (False, True):
             check_rows_option(sg, g, N, narrow=narrow)
         check_hierarchy_block(sg, g, N)
+        for narrow in (False, True):
+            check_flat_loop(sg, g, N, narrow=narrow)
         sg.set_rs_chunks(2)                                  # A'_r's kept columns cut per row chunk
         try:
             for narrow in (False, True):
@@ -252,6 +254,53 @@ def check(kind, device="cpu"):
     finally:
         pkg.enable_activation_reuse(False)
         sg.spmm = real_spmm
+
+
+def check_flat_loop(sg, g, N, dev=None, hidden=16, classes=8, narrow=False):
+    """sharded.FlatLoop against its loop body written out by hand (same switches: bit for bit on one engine) and its
+    global losses against the sum of the ranks' shares."""
+    import pytextgcn_amd as pkg
+    dev = dev if dev is not None else torch.device("cpu")
+    torch.manual_seed(23)
+    init = O.GCNOracle(N, classes, n_hidden_gcn=hidden, dropout=0.0).state_dict()
+    y_l = sg.scatter_rows(g.y.to(dev) % classes)
+    tr_l, va_l = sg.scatter_rows(g.train_mask.to(dev)), sg.scatter_rows(g.val_mask.to(dev))
+
+    def make():
+        m = sharded.ShardedGCN(sg, N, classes, n_hidden_gcn=hidden, dropout=0.0, narrow_exchange=narrow).to(dev)
+        m.load_full_state_dict(init)
+        o = torch.optim.Adam(m.parameters(), lr=0.02, amsgrad=True) if dev.type == "cpu" else \
+            pkg.optim.Adam(m.parameters(), lr=0.02, amsgrad=True)
+        return m, o
+    a, oa = make()
+    with sharded.FlatLoop(a, y_l, tr_l, va_l, optimizer=oa) as loop:
+        got = [loop.epoch() for _ in range(3)]
+    from pytextgcn_amd import conv as conv_
+    assert not conv_._REUSE and loop.epochs == 3
+    b, ob = make()
+    if hasattr(ob, "fuse_into_backward"):
+        ob.fuse_into_backward(b.weights[0])
+    rows_eval = tr_l | va_l
+    pkg.enable_activation_reuse(True)
+    try:
+        for step in range(3):
+            b.train()
+            loss = sharded.sharded_cross_entropy(sg, b(rows=tr_l), y_l, tr_l)
+            ob.zero_grad(set_to_none=True)
+            loss.backward()
+            b.sync_grads()
+            ob.step()
+            b.eval()
+            with torch.no_grad():
+                vl, pred = sharded.sharded_cross_entropy(sg, b(rows=rows_eval), y_l, va_l, return_pred=True)
+            both = torch.stack([loss.detach(), vl.detach()]).float()
+            dist.all_reduce(both)
+            assert got[step][0] == both[0].item() and got[step][1] == both[1].item(), (step, got[step][:2], both)
+            assert (got[step][2] == pred[va_l].cpu().numpy()).all() and (got[step][3] == pred[tr_l].cpu().numpy()).all()
+    finally:
+        pkg.enable_activation_reuse(False)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
 
 
 def check_hierarchy_block(sg, g, N, dev=None, hidden=16, classes=5, F_h=6):
@@ -619,6 +668,8 @@ def check_hip(kind, g, hubs, N, dev):
         check_rows_option(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8, narrow=True, fuse_w1=True)
         # the features [I | H] of the hierarchical scripts on the partition
         check_hierarchy_block(sg, g, N, dev, hidden=F)
+        check_flat_loop(sg, g, N, dev, hidden=F, narrow=False)
+        check_flat_loop(sg, g, N, dev, hidden=F, narrow=True)
     torch.manual_seed(3)
     ref = O.GCNOracle(N, 5, n_hidden_gcn=F, dropout=0.0)
     mine = sharded.ShardedGCN(sg, N, 5, n_hidden_gcn=F, dropout=0.0).to(dev)
