@@ -722,6 +722,9 @@ def flat_loop_epoch_ms(g, F, n_classes, reps=5):
     return sorted(times)[len(times) // 2]
 
 
+SHARDED_EPOCH_LOSS = {}       # variant -> global training loss after the timed epochs (same weights, same masks: must agree)
+
+
 def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w1=False, narrow=False, rows=False):
     """The epoch of flat_amazon.py:99-117 on the row-partitioned model: every rank owns its rows of
     W1 / H1 / logits and of the Adam state; fused loss and optimizer kernels; small dense gradients
@@ -741,8 +744,12 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
     rows_train = train_l if rows else None
     rows_eval = (train_l | val_l) if rows else None
     pkg.enable_activation_reuse(reuse)
-    # narrow: hub rows cross the links at the class width where the activation-free network allows (pytextgcn_amd/narrow.py)
-    model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5, narrow_exchange=narrow).to(dev)
+    # narrow: hub rows cross the links at the class width where the activation-free network allows (pytextgcn_amd/narrow.py).
+    # Every variant starts from the same weights and draws the same KEYED dropout masks (a function of a node's place in
+    # the partition and a seed common to the group), so the losses the variants reach are comparable: SHARDED_EPOCH_LOSS
+    torch.manual_seed(4321)
+    model = ShardedGCN(sg, N, n_classes, n_hidden_gcn=F, dropout=0.5, narrow_exchange=narrow,
+                       keyed_dropout=True if sg.rp > 0 else None).to(dev)
     with torch.no_grad():
         model.weights[0].uniform_(-0.0017, 0.0017)            # glorot bound of an N x h matrix
     opt = pkg.optim.Adam(model.parameters(), lr=0.05, amsgrad=True)
@@ -776,6 +783,10 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
     del model, opt
     t = torch.tensor([sorted(times)[len(times) // 2]], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    total = loss.detach().double().reshape(1).clone()         # the ranks' shares of the last training loss
+    dist.all_reduce(total)
+    SHARDED_EPOCH_LOSS["plain" + ("+reuse" if reuse else "") + ("+w1" if fuse_w1 else "") + ("+narrow" if narrow else "")
+                       + ("+rows" if rows else "")] = total.item()
     return t.item()
 
 
@@ -1372,6 +1383,11 @@ def main():
             "epoch_ms_fused_w1_reuse_narrow_exchange": epoch_ms_narrow,
             # N > 1, opt-in: both at once -- `ShardedGCN.forward(rows=...)` on the narrow exchange
             "epoch_ms_fused_w1_reuse_narrow_exchange_needed_rows_only": epoch_ms_narrow_rows,
+            # N > 1: the global training loss every variant of the sharded epoch reached after its timed epochs -- same
+            # initial weights, same keyed dropout masks, so they must agree to fp32 rounding carried through Adam
+            "sharded_epoch_final_loss": (dict(SHARDED_EPOCH_LOSS, max_rel_spread=(
+                (max(SHARDED_EPOCH_LOSS.values()) - min(SHARDED_EPOCH_LOSS.values())) / abs(min(SHARDED_EPOCH_LOSS.values()))))
+                if SHARDED_EPOCH_LOSS else None),
             "exchange_floats_per_hub_row_and_step": None if parallelism == "single" else {
                 "plain": {"train": 4 * F + 4 * C, "eval": 2 * F + 2 * C},
                 "narrow": {"train": 2 * F + 6 * C, "eval": F + 3 * C},
