@@ -14,10 +14,15 @@ H = torch.randn(N, h, device=dev)
 W = torch.randn(h, C, device=dev)
 G = torch.randn(N, C, device=dev)
 seed = dense.new_seed(dev)
+_, MASK = dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
 for _ in range(5):
     dense.gemm_tn(H, G)
     dense.gemm_tn(H, G, 0.5, seed)
     dense.gemm_nt(G, W)
     dense.gemm_nt(G, W, 0.5, seed, note_colsums=True)
     dense.gemm_nn(H, W)
+    # the epoch's own variants: the forward product draws and records the mask, both gradient products read the record
+    dense.gemm_nn(H, W, 0.5, seed, record_mask=True)
+    dense.gemm_tn(H, G, 0.5, seed, MASK)
+    dense.gemm_nt(G, W, 0.5, seed, note_colsums=True, mask=MASK)
 torch.cuda.synchronize()
