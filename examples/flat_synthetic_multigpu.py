@@ -36,6 +36,9 @@ p.add_argument("--narrow", action="store_true",
 p.add_argument("--rows", action="store_true",
                help="gcn(rows=mask): name the rows of the logits the loop reads (documents only), so the last propagate step "
                     "drops the word rows -- and one collective each way (ShardedGraph.rows_view)")
+p.add_argument("--loop-object", action="store_true",
+               help="run the epochs through pytextgcn_amd.sharded.FlatLoop (W1's update inside the backward SpMM, activation "
+                    "reuse, rows=...: every switch that leaves the numbers alone, behind one object)")
 p.add_argument("--fuse-w1", action="store_true",
                help="update this rank's W1 rows inside the backward SpMM (optim.Adam.fuse_into_backward; takes hidden > 128)")
 args = p.parse_args()
@@ -87,26 +90,38 @@ def accuracy(logits, mask):
     return (hit[0] / hit[1]).item()
 
 
-# --rows: kept tensors (the restricted operators are cached under them); every rank passes a mask in the same call
-rows_train = train_l if args.rows else None
-rows_eval = (train_l | val_l) if args.rows else None
-th.cuda.synchronize()
-t0 = time.time()
-for epoch in range(args.epochs):
-    gcn.train()
-    loss = sharded_cross_entropy(sg, gcn(rows=rows_train), y_l, train_l)
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    gcn.sync_grads()
-    optimizer.step()
-    gcn.eval()
-    with th.no_grad():
-        logits = gcn(rows=rows_eval)
-        acc_val = accuracy(logits, val_l)
-    total = loss.detach().clone()
-    dist.all_reduce(total)
-    if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
-        print(f"[{epoch + 1:3d}] loss: {total.item(): .3f}, val accuracy: {acc_val: .3f}", flush=True)
+if args.loop_object:
+    from pytextgcn_amd.sharded import FlatLoop
+    th.cuda.synchronize()
+    t0 = time.time()
+    with FlatLoop(gcn, y_l, train_l, val_l, optimizer=optimizer) as loop:
+        for epoch in range(args.epochs):
+            loss_, _, pred_val, _ = loop.epoch()                      # global losses; class ids of this rank's rows
+            hit = th.tensor([float((pred_val == y_l[val_l].cpu().numpy()).sum()), float(len(pred_val))], device=dev).double()
+            dist.all_reduce(hit)
+            if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
+                print(f"[{epoch + 1:3d}] loss: {loss_: .3f}, val accuracy: {(hit[0] / hit[1]).item(): .3f}", flush=True)
+else:
+    # --rows: kept tensors (the restricted operators are cached under them); every rank passes a mask in the same call
+    rows_train = train_l if args.rows else None
+    rows_eval = (train_l | val_l) if args.rows else None
+    th.cuda.synchronize()
+    t0 = time.time()
+    for epoch in range(args.epochs):
+        gcn.train()
+        loss = sharded_cross_entropy(sg, gcn(rows=rows_train), y_l, train_l)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        gcn.sync_grads()
+        optimizer.step()
+        gcn.eval()
+        with th.no_grad():
+            logits = gcn(rows=rows_eval)
+            acc_val = accuracy(logits, val_l)
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
+            print(f"[{epoch + 1:3d}] loss: {total.item(): .3f}, val accuracy: {acc_val: .3f}", flush=True)
 th.cuda.synchronize()
 with th.no_grad():
     acc_test = accuracy(gcn(), test_l)
