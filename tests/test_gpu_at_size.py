@@ -278,6 +278,26 @@ def test_config_c4_eight_rank_partition_first_and_last_rank_against_the_oracle(c
                                    acc64=True)
         got = yA[(node_of_hub_row >= 0).cpu()]
         assert rel_err(got, want) < TOL and row_rel_err(got, want) < TOL, (r, rel_err(got, want), row_rel_err(got, want))
+        if r == W - 1:
+            # the operators of `ShardedGCN.forward(rows=...)` at this size (ShardedGraph.rows_view cuts them from the local
+            # operators' own CSR): kept rows of B_r as B_r gives them, every other row the bias; A'_r and B'_r over the kept
+            # columns as the whole operators give them on a gradient whose other rows are zero
+            from pytextgcn_amd.sharded import _RowsView
+            keepm = (torch.rand(rp_, device=cuda, generator=gen) < 0.8) & (own_reg >= 0)
+            view = _RowsView(sg, keepm)
+            assert view.kept_entries["B"] < B.nnz and view.kept_entries["At"] < sg.dirs[1].A.nnz
+            yv, yw = view.B_rows.spmm(xh, bias, x2=xr), B.spmm(xh, bias, x2=xr)
+            assert rel_err(yv[hp:][keepm], yw[hp:][keepm]) < 2e-6
+            assert torch.equal(yv[:hp], bias.expand(hp, -1)) and torch.equal(yv[hp:][~keepm], bias.expand(int((~keepm).sum()), -1))
+            dT = sg.dirs[1]
+            gz = xr * keepm.unsqueeze(1)
+            assert rel_err(view.At.spmm(xr), dT.A.spmm(gz)) < 2e-6
+            whole_t = dT.B.spmm(torch.zeros(W * hp, F, device=cuda), None, x2=gz)
+            assert float(whole_t[:hp].abs().max()) == 0.0          # B'_r's hub rows hold hub columns only
+            assert rel_err(view.Bt_reg.spmm(xr), whole_t[hp:]) < 2e-6
+            _report("c4_partition_rows_view_rank7", kept_regular_rows=int(keepm.sum()), **view.kept_entries,
+                    B_entries=B.nnz, At_entries=dT.A.nnz)
+            del view, yv, yw, gz, whole_t
         for d in sg.dirs:
             d.A.close(), d.B.close()
         del sg, xh, xr, yA, yB
