@@ -658,7 +658,9 @@ def check_hip(kind, g, hubs, N, dev):
         assert rel_err(got.cpu(), ref) < 1e-5, (kind, transpose, rel_err(got.cpu(), ref))
     check_offline_construction(sga, gd, hubs_d, N, engine=sharded.HipEngine())
     del sga
-    if sg.rp > 0:
+    if sg.rp > 0 and dist.get_world_size() <= 3:
+        # (groups of two and three ranks: the four-rank runs keep to the exchange itself -- the suite's wall time; world 4
+        # and 8 run every one of these checks on the CPU engine, tests/test_sharded.py)
         # the narrow exchange against the plain one on the SAME keyed dropout mask (p = 0.5), plain and with W1's Adam
         # update inside the backward SpMM
         check_narrow_exchange(sg, gd, N, dev, dropout=0.5, hidden=F, classes=8)
