@@ -2082,6 +2082,36 @@ def test_flat_loop_is_the_manual_loop_with_every_switch(cuda):
                 assert abs(l - lr_.item()) < 2e-5 * abs(lr_.item()) and abs(v - vr.item()) < 2e-5 * abs(vr.item()), (l, lr_, v, vr)
 
 
+def test_reordered_documents_are_the_same_network_on_the_hip_path(cuda):
+    """pytextgcn_amd.reorder_documents on the device: the plan of the reordered graph holds the original's entries -- same
+    weights bit for bit (the edge order, hence every degree sum, is kept) -- under the new names,
+    and the two-layer network returns the original's logits under the permutation."""
+    N, C = 20000, 8
+    g = synth.word_doc_graph(N, 400000, seed=19, n_classes=C, n_topics=C, doc_order="shuffled", device=cuda)
+    g2, perm = pkg.reorder_documents(g, n_clusters=C)
+    assert perm.device == g.edge_index.device and not torch.equal(perm, torch.arange(N, device=cuda))
+    plan, plan2 = GraphPlan(g.edge_index, g.edge_attr, N), GraphPlan(g2.edge_index, g2.edge_attr, N)
+    (rp, col, val), (rp2, col2, val2) = plan.export_csr(), plan2.export_csr()
+    counts, counts2 = (rp[1:] - rp[:-1]).long(), (rp2[1:] - rp2[:-1]).long()
+    assert torch.equal(counts2, counts[perm])
+    # the plan keeps a row's entries by column id, so the order within a row follows the names: compare entry by entry
+    row = torch.repeat_interleave(torch.arange(N, device=cuda), counts)
+    old_row, old_col = perm[torch.repeat_interleave(torch.arange(N, device=cuda), counts2)], perm[col2.long()]
+    o1, o2 = torch.argsort(row * N + col.long()), torch.argsort(old_row * N + old_col)
+    assert torch.equal(old_row[o2], row[o1]) and torch.equal(old_col[o2], col.long()[o1])
+    assert torch.equal(val2[o2].view(torch.int32), val[o1].view(torch.int32))
+    torch.manual_seed(4)
+    a = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    b = pkg.GCN(N, C, n_hidden_gcn=64, dropout=0.0).to(cuda)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    sd["layers.0.weight"] = sd["layers.0.weight"][perm]
+    b.load_state_dict(sd)
+    a.eval(), b.eval()
+    with torch.no_grad():
+        za, zb = a(g), b(g2)
+    assert rel_err(zb, za[perm]) < 2e-6, rel_err(zb, za[perm])
+
+
 def test_three_layer_gcn_and_general_sparse_features(cuda):
     """n_gcn = 3 (input -> h -> h -> classes, models.py:11-15) and a sparse feature matrix that is NOT
     the identity: X @ W1 and its weight gradient run on the HIP SpMM over a rectangular feature plan

@@ -9,6 +9,8 @@ vocabulary; the same graph is then laid out three ways:
     reordered   the shuffled graph with its documents re-labelled by their RAREST word (document frequency, ties by word
                 id): a plan-level heuristic that needs no topic labels
     reordered_mid   ... by their most frequent word among those in fewer than 2 % of the documents (a topic's head word)
+    propagated      ... by clusters found from the document-word edges alone (`by_propagation`: alternating votes of
+                    documents and words, a few passes over the edges on the GPU)
 
 and timed at F = 200 and F = 64 (one tgcn_spmm launch each, median of interleaved rounds).  With `--one VARIANT F` it runs
 five launches of one variant only, for a `rocprofv3 --pmc FETCH_SIZE` pass (tools/exp_topical_order.sh).
@@ -41,7 +43,12 @@ def by_rarest_word(g, mid_frequency=False):
         key = torch.zeros(N - V, dtype=torch.int64, device=ei.device).scatter_reduce_(0, d, score * V + w, "amax")
     else:
         key = torch.full((N - V,), 1 << 62, dtype=torch.int64, device=ei.device).scatter_reduce_(0, d, df[w] * V + w, "amin")
-    order = torch.argsort(key, stable=True)                          # old document ids in their new order
+    return relabelled(g, torch.argsort(key, stable=True))
+
+
+def relabelled(g, order):
+    """The graph with document `order[i]` (old id, counted from the first document) re-labelled as document i."""
+    V, ei = g.n_vocab, g.edge_index
     new_id = torch.empty_like(order)
     new_id[order] = torch.arange(order.numel(), device=order.device)
     coo = ei.t().clone()                                             # (ei IS the transposed view of a contiguous [E, 2] array)
@@ -51,16 +58,38 @@ def by_rarest_word(g, mid_frequency=False):
     return coo.t(), g.edge_attr
 
 
+def by_propagation(g, K=None, report=None):
+    """Documents laid out by the clusters `pytextgcn_amd.reorder.cluster_documents` finds from the document-word edges alone
+    (the shipped routine: alternating votes of documents and words; no topic labels)."""
+    from pytextgcn_amd.reorder import cluster_documents
+    V, N = g.n_vocab, g.y.numel()
+    lab = cluster_documents(g.edge_index, g.edge_attr, V, N, n_clusters=K)
+    if report is not None:
+        K_ = int(lab.max()) + 1
+        sizes = torch.bincount(lab, minlength=K_)
+        t = g.y[V:].long()                       # the generator's topic of every document (its label): for the report only
+        T_ = int(t.max()) + 1
+        joint = torch.zeros(K_ * T_, device=lab.device).index_add_(0, lab * T_ + t, torch.ones(N - V, device=lab.device))
+        report.update(clusters=K_, largest=int(sizes.max()), purity=round(float(joint.view(K_, T_).max(1).values.sum() / (N - V)), 3))
+    return relabelled(g, torch.argsort(lab, stable=True))
+
+
 def graphs(cfg):
     kw = dict(SHAPES[cfg], seed=44, device=dev, features="none")
     gt = synth.word_doc_graph(**kw, doc_order="by_topic")
     gs = synth.word_doc_graph(**kw, doc_order="shuffled")
     out = {"by_topic": (gt.edge_index, gt.edge_attr), "shuffled": (gs.edge_index, gs.edge_attr),
            "reordered": by_rarest_word(gs), "reordered_mid (most frequent word below 2 % of the documents)": by_rarest_word(gs, True)}
+    T = SHAPES[cfg]["n_topics"]
+    for name, K in (("propagated (K = topics)", T), ("propagated (K = 4 x topics)", 4 * T), ("propagated (K by default)", None)):
+        rep = {}
+        out[name] = by_propagation(gs, K, report=rep)
+        print(f"{cfg} {name}: {rep}", flush=True)
     plain = dict(kw)
     plain.pop("n_topics")
     gp = synth.word_doc_graph(**plain)
     out["no_topics (the benchmark generator)"] = (gp.edge_index, gp.edge_attr)
+    out["no_topics, propagated (nothing to find: must not hurt)"] = by_propagation(gp, None)
     return out, kw["n_nodes"]
 
 
