@@ -23,6 +23,9 @@ p = argparse.ArgumentParser()
 p.add_argument("--docs", type=int, default=5000)
 p.add_argument("--epochs", type=int, default=50)
 p.add_argument("--fused", action="store_true", help="pytextgcn_amd.train.FlatLoop: the same epoch with every switch of the package instead of torch's CE / Adam / dropout")
+p.add_argument("--reorder", action="store_true",
+               help="pytextgcn_amd.reorder_documents: lay the document nodes out by clusters found from the graph (a corpus "
+                    "with topical locality whose file is not sorted by class gathers fewer distinct word rows per stretch)")
 args = p.parse_args()
 
 seed, lr, dropout, window_size, min_df = 44, 0.05, 0.7, 20, 5          # :22-35,66
@@ -36,6 +39,9 @@ t0 = time.time()
 t2g = Text2GraphTransformer(n_jobs=8, min_df=min_df, window_size=window_size, rm_stopwords=False, verbose=1)
 g = t2g.fit_transform(docs, y, test_idx=test_idx, val_idx=val_idx)     # :66-70
 print(f"graph: {g}  ({time.time() - t0:.2f} s)")
+if args.reorder:
+    from pytextgcn_amd import reorder_documents
+    g, perm = reorder_documents(g)     # same graph, other numbering: the loop below addresses nodes through the masks only
 
 gcn = GCN(g.x.shape[1], len(np.unique(y)), n_hidden_gcn=100, dropout=dropout)   # :80
 criterion = th.nn.CrossEntropyLoss(reduction="mean")                   # :82
