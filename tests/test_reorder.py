@@ -45,8 +45,16 @@ def test_reordered_graph_gives_the_oracle_the_same_network():
     are the original's under the permutation (the edge order is kept, so every sum runs over the same terms in the same
     order: bit for bit)."""
     g = _topical(1500, 20000, 5)
+    _check_oracle_network_under(g, *reorder_documents(g, n_clusters=5))
+    g3, perm3 = reorder_documents(g, n_clusters=5, words=True)     # word nodes by cluster as well, inside [0, n_vocab)
+    V = g.n_vocab
+    assert torch.equal(torch.sort(perm3[:V]).values, torch.arange(V)) and not torch.equal(perm3[:V], torch.arange(V))
+    assert torch.equal(perm3[g3.edge_index], g.edge_index) and g3.n_vocab == V
+    _check_oracle_network_under(g, g3, perm3)
+
+
+def _check_oracle_network_under(g, g2, perm):
     N = g.y.numel()
-    g2, perm = reorder_documents(g, n_clusters=5)
     torch.manual_seed(3)
     a = O.GCNOracle(N, 5, n_hidden_gcn=16, dropout=0.0)
     b = copy.deepcopy(a)

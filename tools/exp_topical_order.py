@@ -74,6 +74,24 @@ def by_propagation(g, K=None, report=None):
     return relabelled(g, torch.argsort(lab, stable=True))
 
 
+def words_too(g, K=None):
+    """`by_propagation` and, on top, the WORD nodes laid out by the cluster that holds most of each word's mass (what
+    `reorder_documents(..., words=True)` does)."""
+    from pytextgcn_amd.reorder import cluster_documents
+    V, N = g.n_vocab, g.y.numel()
+    lab = cluster_documents(g.edge_index, g.edge_attr, V, N, n_clusters=K)
+    K_ = int(lab.max()) + 1
+    ei = g.edge_index
+    m = (ei[0] >= V) & (ei[1] < V)
+    d, w, a = ei[0][m] - V, ei[1][m], g.edge_attr[m].float()
+    ws = torch.zeros(V * K_, device=ei.device).index_add_(0, w * K_ + lab[d], a).view(V, K_)
+    wlab = ws.argmax(1)
+    order = torch.cat([torch.argsort(wlab, stable=True), torch.argsort(lab, stable=True) + V])     # old id at each new place
+    new_id = torch.empty_like(order)
+    new_id[order] = torch.arange(N, device=order.device)
+    return new_id[ei], g.edge_attr
+
+
 def graphs(cfg):
     kw = dict(SHAPES[cfg], seed=44, device=dev, features="none")
     gt = synth.word_doc_graph(**kw, doc_order="by_topic")
@@ -85,6 +103,7 @@ def graphs(cfg):
         rep = {}
         out[name] = by_propagation(gs, K, report=rep)
         print(f"{cfg} {name}: {rep}", flush=True)
+    out["propagated, word nodes by cluster as well (words=True)"] = words_too(gs, None)
     plain = dict(kw)
     plain.pop("n_topics")
     gp = synth.word_doc_graph(**plain)
