@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 5
+#define TGCN_ABI_VERSION 6
 
 enum {
     TGCN_OK = 0,
@@ -172,6 +172,19 @@ int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx,
 int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2,
                     int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
                     void *workspace, size_t workspace_bytes, tgcn_stream stream);
+
+/* tgcn_spmm_acc -- the ACCUMULATE form of tgcn_spmm_split:  Y[r, 0:F] += sum_j M(^T)[r, j] * X[j, 0:F]  for every row r
+ * that holds at least one stored entry; a row without entries is neither read nor written, and there is no bias.  No
+ * counterpart in the single-device reference: the 1-D partition of a graph WITHOUT hub structure (BASELINE config 5) cuts a
+ * rank's operator by the origin of its columns into blocks and runs block k -- accumulating into the same Y -- as soon as
+ * the operand rows of exchange stage k have landed, so that stage k + 1 travels under the compute of stage k
+ * (pytextgcn_amd/sharded.py, `exchange="pipeline"`; SURVEY.md 8(e) "run local part while halo is in flight").  A row is owned
+ * by one wavefront and launches on one stream are ordered, so the sums are reproducible run to run (their association
+ * differs from the one-launch product's: block partial sums are added in launch order).  X2 = NULL: single operand.
+ * Workspace: tgcn_spmm_workspace_bytes(plan, transpose, F). */
+int tgcn_spmm_acc(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2, int64_t ldx2,
+                  int64_t split, int F, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
+                  tgcn_stream stream);
 
 /* tgcn_spmm_adam -- tgcn_spmm whose result rows are never stored: row r of M(^T) @ G is the GRADIENT of row r of
  * `param` and is spent at once on torch.optim.Adam's update of that row (the arithmetic of tgcn_adam_step, op for

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, E_INVALID, E_RANGE, E_HIP, E_NOMEM, E_WORKSPACE = 0, -1, -2, -3, -4, -5
 NORM_OFF, NORM_ACCURATE, NORM_REFERENCE = 0, 1, 2          # `normalize` of tgcn_plan_create
@@ -42,6 +42,8 @@ SIGNATURES = {
                           c_void_p, c_size_t, c_void_p]),
     "tgcn_spmm_split": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "tgcn_spmm_acc": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
+                              c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "tgcn_spmm_adam": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p,
                                c_void_p, c_size_t, c_void_p]),

@@ -91,7 +91,7 @@ int build_items(CsrBlock &b, int item_weight, hipStream_t stream);
 
 // Kernel launchers (spmm.hip / colsum.hip); arguments validated by the caller.
 int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
-                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream);
+                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream, bool acc = false);
 int launch_colsum(const float *G, int64_t ldg, int64_t n_rows, int F, float *out, float *partial,
                   int n_blocks, hipStream_t stream);
 int colsum_blocks(int64_t n_rows);

@@ -133,7 +133,10 @@ __device__ __forceinline__ void adam_update(const AdamRow &ad, int64_t off, cons
 // (col,val) stream, 2 = non-temporal result stores.  The gathered rows themselves always use plain
 // loads: a non-temporal hint on them destroys the L2 / Infinity-Cache re-use (7.5 ms instead of 4.4),
 // and even a per-entry "cold column" hint behind a branch cost more than it saved.
-template <int VEC, int U, int POLICY, bool ADAM = false>
+// ACC (tgcn_spmm_acc): the finished sum is ADDED to the row already in Y, and a row without stored entries is neither
+// read nor written -- the column-block launches of the pipelined exchange (pytextgcn_amd/sharded.py) each touch only the
+// rows they have entries for.  Rows are wave-owned and launches stream-ordered, so the result stays deterministic.
+template <int VEC, int U, int POLICY, bool ADAM = false, bool ACC = false>
 __device__ __forceinline__ void spmm_item(
     const WorkItem it, const int lane, const int col0, const int F,
     const int32_t *__restrict__ rowptr, const int2 *__restrict__ cv, const float *__restrict__ X,
@@ -141,6 +144,7 @@ __device__ __forceinline__ void spmm_item(
     const float *__restrict__ bias, float *__restrict__ Y, const int64_t ldy,
     float *__restrict__ carry, const int64_t ldc, const AdamRow ad = AdamRow{}) {
     static_assert(!ADAM || VEC == 4, "the fused optimizer epilogue is written for float4 lanes");
+    static_assert(!(ADAM && ACC), "the optimizer epilogue consumes the row: nothing to accumulate into");
     using V = Vec<VEC>;
     using vec_t = typename V::type;
     const int nvec = (min(F - col0, 64 * VEC) + VEC - 1) / VEC;  // vectors in this column tile
@@ -191,6 +195,7 @@ __device__ __forceinline__ void spmm_item(
         }
         if (!segment && r < it.row_end && active) adam_prefetch(ad, int64_t(r) * ad.ld + lc, ast);
     }
+    bool touched = false;        // ACC: row r has had an entry (wave-uniform: idx and row_end are)
     auto finish_row = [&]() {
         if constexpr (ADAM) {
             if (active) {
@@ -198,6 +203,12 @@ __device__ __forceinline__ void spmm_item(
                 adam_update(ad, int64_t(r) * ad.ld + lc, g, ast, a_step, a_ibc2);
                 if (r + 1 < it.row_end) adam_prefetch(ad, int64_t(r + 1) * ad.ld + lc, ast);
             }
+        } else if constexpr (ACC) {
+            if (touched) {
+                float *dst = Y + int64_t(r) * ldy + lc;
+                if (active) *reinterpret_cast<vec_t *>(dst) = V::add(*reinterpret_cast<const vec_t *>(dst), acc);
+            }
+            touched = false;
         } else {
             store_row(Y + int64_t(r) * ldy + lc, V::add(acc, bvec));
         }
@@ -239,6 +250,7 @@ __device__ __forceinline__ void spmm_item(
                     if (!segment) {
                         while (idx == row_end) flush_row();
                     }
+                    if constexpr (ACC) touched = true;
                     V::fma(acc, v[u], x[u]);
                 }
             }
@@ -258,7 +270,7 @@ __device__ __forceinline__ void spmm_item(
 }
 
 // grid.x = ceil(n_items / 4), grid.y = column tiles of 64*VEC floats; one item per wavefront
-template <int VEC, int U, int POLICY>
+template <int VEC, int U, int POLICY, bool ACC = false>
 __global__ __launch_bounds__(256) void k_spmm_gather(
     const WorkItem *__restrict__ items, int n_items, const int32_t *__restrict__ rowptr,
     const int2 *__restrict__ cv, const float *__restrict__ X, int64_t ldx,
@@ -268,8 +280,8 @@ __global__ __launch_bounds__(256) void k_spmm_gather(
     const int item_id =
         __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (item_id >= n_items) return;
-    spmm_item<VEC, U, POLICY>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, X2, ldx2,
-                              split, bias, Y, ldy, carry, ldc);
+    spmm_item<VEC, U, POLICY, false, ACC>(items[item_id], lane, blockIdx.y * (64 * VEC), F, rowptr, cv, X, ldx, X2, ldx2,
+                                          split, bias, Y, ldy, carry, ldc);
 }
 
 // The same kernel with the optimizer in its epilogue.  U = 4: the 16 registers of optimizer state in flight take
@@ -309,7 +321,7 @@ typedef float pk_f2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kOobOffset = 0xFFFFF000u;
 static_assert(kOobOffset > 0xFFFF0000u && kOobOffset + 63u * 16u > kOobOffset, "padding offset must stay out of bounds");
 
-template <int G, int U>
+template <int G, int U, bool ACC = false>
 __global__ __launch_bounds__(256) void k_spmm_subb(
     const WorkItem *__restrict__ items, int n_items,
     const int2 *__restrict__ cv, const float *__restrict__ X, unsigned ldx4 /* row stride in bytes */,
@@ -392,6 +404,14 @@ __global__ __launch_bounds__(256) void k_spmm_subb(
             const int b = ri.x, e = ri.y, r = ri.z;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (b < e) acc = run(b, 1, e);
+            if constexpr (ACC) {                               // rows without entries are not touched
+                if (b < e && active) {
+                    float4 *dst = reinterpret_cast<float4 *>(Y + int64_t(r) * ldy + lane_off / 4);
+                    const float4 y0 = *dst;
+                    *dst = make_float4(y0.x + acc.x, y0.y + acc.y, y0.z + acc.z, y0.w + acc.w);
+                }
+                continue;
+            }
             if (active)
                 *reinterpret_cast<float4 *>(Y + int64_t(r) * ldy + lane_off / 4) =
                     make_float4(acc.x + bvec.x, acc.y + bvec.y, acc.z + bvec.z, acc.w + bvec.w);
@@ -492,7 +512,7 @@ __global__ __launch_bounds__(64 * kHotWaves) void k_spmm_hot(
 
 // One workgroup per long row: Y[row] = bias + carry[slot_begin] + ... + carry[slot_begin+count-1].
 // Wave w adds slots w, w+4, ...; the four partials are combined through LDS in wave order.
-template <int VEC, bool ADAM = false>
+template <int VEC, bool ADAM = false, bool ACC = false>
 __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ fix,
                                                   const float *__restrict__ carry, int64_t ldc,
                                                   const float *__restrict__ bias,
@@ -541,7 +561,9 @@ __global__ __launch_bounds__(256) void k_spmm_fix(const FixEntry *__restrict__ f
             adam_update(ad, off, t, st, ad.dev_scalars ? ad.dev_scalars[0] : ad.step_size,
                         ad.dev_scalars ? ad.dev_scalars[1] : ad.inv_bc2_sqrt);
         } else {
-            *reinterpret_cast<vec_t *>(Y + int64_t(fe.row) * ldy + lc) = t;
+            vec_t *dst = reinterpret_cast<vec_t *>(Y + int64_t(fe.row) * ldy + lc);
+            if constexpr (ACC) t = V::add(*dst, t);            // (a long row always holds entries)
+            *dst = t;
         }
     }
 }
@@ -554,11 +576,12 @@ void launch_hot(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
                                                        carry, ldc, b.hot_slot_base, b.hot_parts, b.n_hot);
 }
 
-// `ad` != nullptr (VEC == 4 only): the finished rows are spent on the optimizer instead of being stored in Y
+// `ad` != nullptr (VEC == 4 only): the finished rows are spent on the optimizer instead of being stored in Y;
+// `acc`: the accumulate form (Y += M X on the rows that hold entries; no bias)
 template <int VEC>
 int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream,
-               const AdamRow *ad = nullptr) {
+               const AdamRow *ad = nullptr, const bool acc = false) {
     const int tiles = (F + 64 * VEC - 1) / (64 * VEC);
     const int64_t ldc = round_up4(F);
     // With a dense hot block the float4 kernels run on the partition without the hot rows, next to
@@ -604,18 +627,28 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
             // narrow feature rows (the layer-2 width C): sub-group kernel.  U = 4 gathers in flight per sub-group:
             // 8 / 16 measured 8 % / 6 % slower at F = 64 (c4), document rows hold ~10 entries and every started
             // group of U is gathered in full (with the rows of a block sorted by degree 2 / 8 measured 10 % / 8 % slower)
-            if (F <= 64)
-                k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
-                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
+            const unsigned ldx4 = static_cast<unsigned>(ldx * 4), xb = static_cast<unsigned>(x_extent);
+            if (F <= 64 && !acc)
+                k_spmm_subb<16, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, ldx4, xb, F, bias, Y, ldy, carry, ldc,
+                                                            blk.row_info);
+            else if (F <= 64)
+                k_spmm_subb<16, 4, true><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, ldx4, xb, F, bias, Y, ldy, carry,
+                                                                  ldc, blk.row_info);
+            else if (!acc)
+                k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, ldx4, xb, F, bias, Y, ldy, carry, ldc,
                                                             blk.row_info);
             else
-                k_spmm_subb<32, 4><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, static_cast<unsigned>(ldx * 4),
-                                                            static_cast<unsigned>(x_extent), F, bias, Y, ldy, carry, ldc,
-                                                            blk.row_info);
+                k_spmm_subb<32, 4, true><<<grid, 256, 0, stream>>>(b.items, b.n_items, cv, X, ldx4, xb, F, bias, Y, ldy, carry,
+                                                                  ldc, blk.row_info);
         } else {
             // full-wave kernel: wide rows, split operands, operands beyond 4 GB, unaligned / odd widths (VEC = 1).
             // Streams ((col,val) pairs, result rows) are marked non-temporal on the float4 path (measured best on c4)
-            if constexpr (VEC == 4)
+            // (the accumulate form reads the rows it adds to and the next column block reads them again: plain stores)
+            if (acc) {
+                constexpr int P = VEC == 4 ? 1 : 0;
+                k_spmm_gather<VEC, 8, P, true><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split,
+                                                                         F, bias, Y, ldy, carry, ldc);
+            } else if constexpr (VEC == 4)
                 k_spmm_gather<4, 8, 3><<<grid, 256, 0, stream>>>(b.items, b.n_items, rowptr, cv, X, ldx, X2, ldx2, split, F,
                                                                  bias, Y, ldy, carry, ldc);
             else
@@ -628,6 +661,8 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
         dim3 grid(b.n_fix, tiles);
         if (ad != nullptr) {
             if constexpr (VEC == 4) k_spmm_fix<4, true><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, nullptr, 0, F, *ad);
+        } else if (acc) {
+            k_spmm_fix<VEC, false, true><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, Y, ldy, F);
         } else {
             k_spmm_fix<VEC><<<grid, 256, 0, stream>>>(b.fix, carry, ldc, bias, Y, ldy, F);
         }
@@ -639,7 +674,7 @@ int launch_vec(const CsrBlock &blk, const float *X, int64_t ldx, const float *X2
 }  // namespace
 
 int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2, int64_t ldx2, int split,
-                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream) {
+                int F, const float *bias, float *Y, int64_t ldy, float *carry, hipStream_t stream, bool acc) {
     if (X2 == nullptr) {  // single operand
         X2 = X;
         ldx2 = ldx;
@@ -649,8 +684,8 @@ int launch_spmm(const CsrBlock &b, const float *X, int64_t ldx, const float *X2,
                             reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias) |
                             reinterpret_cast<uintptr_t>(carry);
     const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldx2 % 4 == 0) && (ldy % 4 == 0) && (align % 16 == 0);
-    return vec4 ? launch_vec<4>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream)
-                : launch_vec<1>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream);
+    return vec4 ? launch_vec<4>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream, nullptr, acc)
+                : launch_vec<1>(b, X, ldx, X2, ldx2, split, F, bias, Y, ldy, carry, stream, nullptr, acc);
 }
 
 // the SpMM whose rows feed the optimizer (tgcn_spmm_adam); float4 path only, checked by the caller
@@ -663,6 +698,11 @@ int launch_spmm_adam(const CsrBlock &b, const float *X, int64_t ldx, const float
     }
     return launch_vec<4>(b, X, ldx, X2, ldx2, split, F, nullptr, nullptr, 0, carry, stream, &ad);
 }
+
+// tgcn_spmm_split / tgcn_spmm_acc behind one set of argument checks (below)
+int spmm_entry(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2, int64_t ldx2,
+               int64_t split, int F, const float *bias, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
+               tgcn_stream stream, bool acc);
 
 }  // namespace tgcn
 
@@ -755,7 +795,24 @@ int tgcn_spmm(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx,
 int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2,
                     int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
                     void *workspace, size_t workspace_bytes, tgcn_stream stream) {
-    using namespace tgcn;
+    return tgcn::spmm_entry(plan, transpose, X, ldx, X2, ldx2, split, F, bias, Y, ldy, workspace, workspace_bytes, stream,
+                            false);
+}
+
+int tgcn_spmm_acc(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2, int64_t ldx2,
+                  int64_t split, int F, float *Y, int64_t ldy, void *workspace, size_t workspace_bytes,
+                  tgcn_stream stream) {
+    return tgcn::spmm_entry(plan, transpose, X, ldx, X2, ldx2, split, F, nullptr, Y, ldy, workspace, workspace_bytes,
+                            stream, true);
+}
+
+}  // extern "C"
+
+namespace tgcn {
+
+int spmm_entry(const tgcn_plan *plan, int transpose, const float *X, int64_t ldx, const float *X2,
+               int64_t ldx2, int64_t split, int F, const float *bias, float *Y, int64_t ldy,
+               void *workspace, size_t workspace_bytes, tgcn_stream stream, bool acc) {
     if (!plan || !X || !Y) {
         set_error("tgcn_spmm: NULL plan/X/Y");
         return TGCN_E_INVALID;
@@ -789,9 +846,9 @@ int tgcn_spmm_split(const tgcn_plan *plan, int transpose, const float *X, int64_
     if (cur != plan->device) TGCN_HIP_CHECK(hipSetDevice(plan->device));
     const int st = launch_spmm(b, X, ldx, X2, ldx2, static_cast<int>(split), F, bias, Y, ldy,
                                need ? static_cast<float *>(workspace) : nullptr,
-                               static_cast<hipStream_t>(stream));
+                               static_cast<hipStream_t>(stream), acc);
     if (cur != plan->device) (void)hipSetDevice(cur);
     return st;
 }
 
-}  // extern "C"
+}  // namespace tgcn

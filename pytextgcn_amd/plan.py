@@ -247,9 +247,11 @@ class GraphPlan:
 
     # -- compute ----------------------------------------------------------------------------
     def spmm(self, x: Tensor, bias: Optional[Tensor] = None, transpose: bool = False,
-             out: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
+             out: Optional[Tensor] = None, x2: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
         """out[r] = sum_j M(^T)[row_begin + r, j] x[j] (+ bias); x is [num_nodes, F] fp32.
-        With `x2` the operand is split: columns [0, len(x)) read x, the remaining ones x2."""
+        With `x2` the operand is split: columns [0, len(x)) read x, the remaining ones x2.
+        `accumulate` (`tgcn_spmm_acc`): the sums are ADDED to `out` (required, no bias) on the rows that hold entries;
+        rows without entries are not touched."""
         _require_cuda(x, "x")
         if x.dtype != torch.float32 or x.dim() != 2:
             raise TypeError(f"spmm operand must be a 2-D float32 tensor, got {x.dtype} {tuple(x.shape)}")
@@ -276,12 +278,20 @@ class GraphPlan:
             bias = bias.detach().float().contiguous()
             if bias.numel() != F:
                 raise ValueError(f"bias has {bias.numel()} entries for F={F}")
+        if accumulate and (out is None or bias is not None):
+            raise ValueError("accumulate=True adds into `out` (required) and takes no bias")
         if out is None:
             out = torch.empty(n_out, F, dtype=torch.float32, device=x.device)
-        elif out.shape != (n_out, F) or out.dtype != torch.float32 or out.stride(1) != 1:
-            raise ValueError("`out` must be float32 [n_rows, F] with unit column stride")
+        elif out.shape != (n_out, F) or out.dtype != torch.float32 or out.stride(1) != 1 or out.device != x.device:
+            raise ValueError("`out` must be float32 [n_rows, F] with unit column stride on the operand's device")
         ws = self._workspace(int(transpose), F, x.device)
         ws_bytes = ws.numel() if ws is not None else 0
+        if accumulate:
+            _lib.check(self._lib.tgcn_spmm_acc(
+                self._h, int(transpose), x.data_ptr(), x.stride(0),
+                x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, split, F,
+                out.data_ptr(), out.stride(0), ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(x.device)))
+            return out
         _lib.check(self._lib.tgcn_spmm_split(
             self._h, int(transpose), x.data_ptr(), x.stride(0),
             x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, split, F,

@@ -23,6 +23,12 @@ with a local SpMM.  Edges between regular nodes of different ranks are not repre
 all-gather of the row-sharded operand.  M^T uses the same operators when M is symmetric (TextGCN
 graphs are, text2graph.py:148-171), otherwise a second pair is built from M^T.
 
+Graphs WITHOUT hub structure (`hubs=None`, BASELINE config c5) have no A_r whose SpMM could cover the gather; there the
+default exchange is the PIPELINE (`_Pipeline`): B_r is cut by the origin of its columns into an own-column block, which
+starts at once on the rank's own rows, and K stage blocks; the referenced operand rows travel in K all-to-all stages
+(every link busy in every stage), and block k is ADDED to the result (`tgcn_spmm_acc`) as soon as stage k has landed --
+stage k + 1 is in flight under the compute of stage k ("run local part while halo is in flight").
+
 Local layout on every rank: rows [0, hp) = own hub shard, rows [hp, hp + rp) = own regular shard
 (`owned` maps them to global node ids, -1 = padding row).
 """
@@ -363,13 +369,114 @@ class _Direction:
         self.chunks = {}               # K -> [_Chunk] (K = 1: the whole A_r)
         self.need_cols = None          # halo: gathered-block rows (owner * hp + slot) B_r references, sorted
         self.need_counts = None        #       ... how many of them every rank owns
+        self.need_counts_l = self.send_counts_l = None
         self.send_slots = None         #       own hub slots every peer needs, concatenated in rank order
         self.send_counts = None
+        self.pipes = {}                # (K, scheme) -> _Pipeline (hub-less graphs: B_r cut by the origin of its columns)
 
     @property
     def A(self):
         ch = self.chunks.get(1)
         return ch[0].op if ch else None
+
+
+class _Stage:
+    """One stage of the pipelined exchange: the own slots that leave (`send_slots`, peers in rank order, `send_counts` rows
+    each), the rows that arrive (`recv_counts`, rank order -- they form the stage's operand as they land, no scatter) and
+    the block of B_r whose columns they are (`op`: [hp x sum(recv_counts)], None when it holds no entries)."""
+    __slots__ = ("send_slots", "send_counts", "recv_counts", "op", "nnz")
+
+    def __init__(self, send_slots, send_counts, recv_counts, op, nnz):
+        self.send_slots, self.send_counts, self.recv_counts, self.op, self.nnz = send_slots, send_counts, recv_counts, op, nnz
+
+
+class _Pipeline:
+    """B_r of a graph without hub structure (rp == 0: rows = the rank's hp nodes, columns = the gathered block [W * hp]) cut
+    by the ORIGIN of its columns:
+
+        own      columns owned by this rank                    operand = the rank's own rows, in place: starts at once
+        stage k  columns whose rows arrive in exchange stage k  operand = the stage's receive buffer as it lands
+
+    Which stage a referenced row (owner q, position j of the n rows this rank reads from q) travels in:
+        scheme "slices"  k = j * K // n : every stage is an all-to-all over ALL peers carrying 1 / K of each peer's rows --
+                         on the xGMI mesh every pair of GPUs has its own link, so every link is busy in every stage;
+        scheme "peer"    k = (rank - q) mod W - 1 : stage k is the whole contribution of ONE peer (W - 1 stages; rank r
+                         sends to r + k + 1 while it receives from r - k - 1: a ring shift per stage, one link each way).
+    Both ends evaluate the same formula, so the lists need no further agreement beyond the halo lists.  The stage blocks
+    ACCUMULATE into the result of the own block (`GraphPlan.spmm(accumulate=True)` = `tgcn_spmm_acc`): rows without entries
+    in a block are not touched, the order of the additions is the launch order -- deterministic.  Built from B_r's own CSR:
+    same entries, same order within (row, block)."""
+
+    def __init__(self, sg: "ShardedGraph", d: _Direction, K: int, scheme: str):
+        W, hp, r = sg.world, sg.hp, sg.rank
+        if sg.rp != 0:
+            raise ValueError("the pipelined exchange serves graphs without hub structure (hubs=None)")
+        if scheme not in ("slices", "peer"):
+            raise ValueError('pipeline scheme must be "slices" or "peer"')
+        self.scheme = scheme
+        self.K = K = (W - 1 if scheme == "peer" else max(1, int(K)))
+        dev = d.need_cols.device
+
+        def stage_of(owner, receiver, j, n):
+            """Stage of position j (of n) in the list of rows `receiver` reads from `owner` (tensors or ints; -1 = own)."""
+            if scheme == "peer":
+                return (receiver - owner) % W - 1
+            return (j * K) // n.clamp_min(1) if torch.is_tensor(n) else (j * K) // max(n, 1)
+
+        # receive side: the rows this rank reads (need_cols, sorted: owner-major), their position in the owner's list
+        need = d.need_cols
+        n_owner = need // hp
+        counts = torch.bincount(n_owner, minlength=W)
+        starts = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(need.numel(), device=dev) - starts[n_owner]
+        n_stage = stage_of(n_owner, r, pos, counts[n_owner])
+        n_stage = torch.where(n_owner == r, torch.full_like(n_stage, -1), n_stage)
+        # column of the stage's receive buffer a needed row lands in: rank order, then list order (all_to_all_single)
+        key = (n_stage + 1) * (W * hp) + need                         # (stage, owner, slot): `need` is already owner-major
+        order = torch.argsort(key, stable=True)
+        per_stage = torch.bincount(n_stage[order] + 1, minlength=K + 1)
+        stage_start = torch.cumsum(per_stage, 0) - per_stage
+        landing = torch.empty_like(need)
+        landing[order] = torch.arange(need.numel(), device=dev) - stage_start[n_stage[order] + 1]
+        # gathered-block row -> (stage, landing column); own rows: the slot itself (operand = x_local in place)
+        col_stage = torch.full((W * hp,), -2, dtype=torch.int64, device=dev)
+        col_land = torch.zeros(W * hp, dtype=torch.int64, device=dev)
+        col_stage[need] = n_stage
+        col_land[need] = torch.where(n_owner == r, need - r * hp, landing)
+        recv_counts = torch.zeros(K, W, dtype=torch.int64, device=dev)
+        rem = n_owner != r
+        recv_counts.index_put_((n_stage[rem], n_owner[rem]), torch.ones_like(need[rem]), accumulate=True)
+        # send side: my slots every peer reads (send_slots, peers in rank order), cut by the SAME formula
+        s_peer = torch.repeat_interleave(torch.arange(W, device=dev), d.send_counts.to(dev))
+        s_starts = torch.cumsum(d.send_counts.to(dev), 0) - d.send_counts.to(dev)
+        s_pos = torch.arange(s_peer.numel(), device=dev) - s_starts[s_peer]
+        s_stage = stage_of(r, s_peer, s_pos, d.send_counts.to(dev)[s_peer])
+        s_rem = s_peer != r
+        send_counts = torch.zeros(K, W, dtype=torch.int64, device=dev)
+        send_counts.index_put_((s_stage[s_rem], s_peer[s_rem]), torch.ones_like(s_peer[s_rem]), accumulate=True)
+        # the blocks, from B_r's own CSR
+        rowptr, col, val = d.B.export_csr()
+        row = torch.repeat_interleave(torch.arange(hp, device=col.device), (rowptr[1:] - rowptr[:-1]).long())
+        col = col.long()
+        e_stage, e_col = col_stage[col], col_land[col]
+        if bool((e_stage < -1).any()):
+            raise RuntimeError("sharded: B_r references a column outside its own need list")
+        sel = e_stage == -1
+        self.own = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, hp)
+        self.own_nnz = int(sel.sum())
+        rc, sc = recv_counts.tolist(), send_counts.tolist()
+        self.stages = []
+        for k in range(K):
+            sel = e_stage == k
+            nnz = int(sel.sum())
+            n_cols = int(sum(rc[k]))
+            op = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, n_cols) if (nnz and n_cols) else None
+            slots = d.send_slots[s_rem & (s_stage == k)].contiguous()      # peers in rank order, list order within a peer
+            sg._check_list(slots, hp, "pipeline send slots")
+            self.stages.append(_Stage(slots, [int(v) for v in sc[k]], [int(v) for v in rc[k]], op, nnz))
+
+    def rows_received(self) -> int:
+        return int(sum(sum(st.recv_counts) for st in self.stages))
 
 
 class _RowsView:
@@ -415,7 +522,8 @@ class _RowsView:
 
 class ShardedGraph:
     _CHUNK = 1 << 23      # edges per pass of the local-operator construction (transients stay O(chunk))
-    EXCHANGES = ("collective", "p2p", "halo")
+    EXCHANGES = ("collective", "p2p", "halo")          # forms every partition serves; "pipeline": hub-less graphs only
+    PIPE_STAGES_MAX = 8
 
     def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
                  group=None, hubs: Optional[Tensor] = None, add_self_loops=True,
@@ -443,12 +551,72 @@ class ShardedGraph:
         #                 without hub structure (hubs=None) this is the true halo exchange.
         # TGCN_EXCHANGE pins the form, TGCN_RS_CHUNKS the number of row chunks A_r runs in (each chunk's
         # reduce-scatter starts when its rows are finished); bench.py times a few steps of each and keeps the fastest.
+        #   "pipeline"    graphs without hub structure only (hubs=None; their DEFAULT): the halo rows travel in K stages and
+        #                 the column block of stage k is added to the result while stage k + 1 is in flight (`_Pipeline`);
+        #                 TGCN_PIPE_STAGES / TGCN_PIPE_SCHEME pin K and the scheme (`set_pipeline`).
         import os
         self._build_halo_lists()
         self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
-        self.exchange = os.environ.get("TGCN_EXCHANGE", "collective")
-        if self.exchange not in self.EXCHANGES:
-            raise ValueError(f"TGCN_EXCHANGE must be one of {self.EXCHANGES}")
+        self.set_pipeline(os.environ.get("TGCN_PIPE_STAGES"), os.environ.get("TGCN_PIPE_SCHEME", "slices"))
+        # a graph without hub structure has nothing to cover a whole-operand all-gather with: only the referenced rows
+        # travel, pipelined under the column blocks; a hub partition overlaps its two collectives with A_r / B_r
+        self.exchange = os.environ.get("TGCN_EXCHANGE", "pipeline" if self.rp == 0 else "collective")
+
+    @property
+    def exchange(self) -> str:
+        return self._exchange
+
+    @exchange.setter
+    def exchange(self, form: str) -> None:
+        if form == "pipeline":
+            if self.rp != 0:
+                raise ValueError('exchange="pipeline" serves graphs without hub structure (hubs=None); a hub partition '
+                                 f"takes one of {self.EXCHANGES}")
+        elif form not in self.EXCHANGES:
+            raise ValueError(f"the exchange form must be one of {self.EXCHANGES + ('pipeline',)}, got {form!r}")
+        self._exchange = form
+
+    def set_pipeline(self, K=None, scheme: str = "slices") -> None:
+        """Number of stages and scheme of the pipelined exchange (`_Pipeline`; hub-less graphs).  K = None: from the bytes
+        -- a stage should still carry ~32 MB per peer at the hidden width (256 floats) so that the links run at their
+        rate, at most PIPE_STAGES_MAX stages.  The blocks are cut on first use and kept per (K, scheme); local (the halo
+        lists are agreed on already), but every rank must choose the same K and scheme."""
+        if self.rp != 0:
+            self.pipe_stages, self.pipe_scheme = 0, scheme
+            return
+        if K is None or K == "":
+            d = self.dirs[0]
+            own = d.need_counts_l[self.rank] if d.need_counts_l is not None else 0
+            per_peer = (sum(d.need_counts_l) - own) / max(1, self.world - 1) if d.need_counts_l is not None else 0
+            if self.group is not None and self.world > 1:            # the same K everywhere: the largest rank decides
+                t = torch.tensor([float(per_peer)], device=self._comm_device())
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                per_peer = float(t.item())
+            K = int(per_peer * 1024 // (32 << 20))
+        self.pipe_stages = max(1, min(int(K), self.PIPE_STAGES_MAX))
+        self.pipe_scheme = scheme
+        if scheme not in ("slices", "peer"):
+            raise ValueError('pipeline scheme must be "slices" or "peer"')
+
+    def _pipeline(self, d: _Direction) -> _Pipeline:
+        key = (self.pipe_stages, self.pipe_scheme)
+        pipe = d.pipes.get(key)
+        if pipe is None:
+            if d.send_slots is None:
+                raise RuntimeError("the pipelined exchange needs the halo lists (for_rank(..., halo_lists=True))")
+            pipe = d.pipes[key] = _Pipeline(self, d, *key)
+        return pipe
+
+    def drop_unused_pipelines(self) -> None:
+        """Release the column blocks of every (K, scheme) but the current one (bench.py times a few)."""
+        keep = (self.pipe_stages, self.pipe_scheme)
+        for d in self.dirs:
+            for key in [k for k in d.pipes if k != keep]:
+                pipe = d.pipes.pop(key)
+                for op in [pipe.own] + [st.op for st in pipe.stages]:
+                    close = getattr(op, "close", None)
+                    if close is not None:
+                        close()
 
     @classmethod
     def for_rank(cls, edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, world: int, rank: int,
@@ -465,9 +633,11 @@ class ShardedGraph:
         self.group = None
         self._setup(edge_index, edge_weight, num_nodes, int(world), int(rank), hubs, add_self_loops, normalize, engine,
                     symmetric, degree_sum)
-        self.exchange = "collective"
+        self._exchange = "collective"
+        self.pipe_stages, self.pipe_scheme = 0, "slices"
         if halo_lists:
             self._build_halo_lists_offline(edge_index)
+            self.set_pipeline(None)
         return self
 
     def _build_halo_lists_offline(self, edge_index: Tensor) -> None:
@@ -821,6 +991,8 @@ class ShardedGraph:
         hp = self.hp
         shard = x_local[:hp]
         direct = self._stream_ordered(x_local)
+        if self._exchange == "pipeline":
+            raise RuntimeError("the pipelined exchange has no gather step of its own (ShardedGraph._spmm_pipeline)")
         if self.exchange == "collective":
             xbuf = self._gather_buffer(x_local, False)
             work = dist.all_gather_into_tensor(xbuf, shard, group=self.group, async_op=True)
@@ -939,6 +1111,8 @@ class ShardedGraph:
         if x_local.shape[0] != self.n_local:
             raise ValueError(f"operand has {x_local.shape[0]} rows, this rank owns {self.n_local}")
         x_local = x_local.contiguous()
+        if self._exchange == "pipeline":
+            return self._spmm_pipeline(d, x_local, bias)
         xbuf, gathered = self._start_gather(d, x_local)
         pending = []
         if d.A is not None:
@@ -952,6 +1126,24 @@ class ShardedGraph:
         y = self._apply_B(d, x_local, bias, xbuf, whole)                    # overlaps the reduce-scatter
         for finish in pending:
             finish(y[:hp])
+        return y
+
+    def _spmm_pipeline(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor]) -> Tensor:
+        """The distributed SpMM of a graph without hub structure: every stage's rows are packed and its all-to-all posted
+        up front (the communicator's stream runs them one after the other beside the compute stream), the own-column block
+        starts at once, and block k is added as soon as stage k has landed."""
+        pipe = self._pipeline(d)
+        direct = self._stream_ordered(x_local)
+        key = self.dirs.index(d)
+        posted = []
+        for k, st in enumerate(pipe.stages):
+            pack = self._rows_gather(x_local, st.send_slots)
+            posted.append(self._all_to_all_v(pack, st.recv_counts, st.send_counts, direct, role=("pipe", key, pipe.K, k)))
+        y = pipe.own.spmm(x_local, bias)                       # overlaps the first stage
+        for st, (recv, work) in zip(pipe.stages, posted):
+            work.wait()
+            if st.op is not None:
+                st.op.spmm(recv, out=y, accumulate=True)       # overlaps the next stage
         return y
 
     def _apply_B(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor], xbuf: Tensor, whole: Optional[Tensor]) -> Tensor:
@@ -1013,8 +1205,14 @@ class ShardedGraph:
         hp, rp = self.hp, self.rp
         if g_local.size(1) <= self._NARROW:
             raise ValueError("spmm_adam_w1 serves the wide (hidden) width only")
-        self._split_B(d)
         g_local = g_local.contiguous()
+        if self._exchange == "pipeline":
+            # no regular rows: every gradient row is complete only after the last stage block -- the plain road
+            if hub_block is not None or g_local.shape[0] != self.n_local:
+                raise ValueError("the pipelined exchange takes the rank's whole operand")
+            adam(slice(0, hp), self._spmm_pipeline(d, g_local, None), None, None, None)
+            return
+        self._split_B(d)
         if hub_block is None:
             if g_local.shape[0] != self.n_local:
                 raise ValueError(f"operand has {g_local.shape[0]} rows, this rank owns {self.n_local}")
@@ -1118,6 +1316,8 @@ class ShardedGraph:
         d = self.dirs[0]
         out = {"gather_all": (self.world - 1) * self.hp,
                "gather_halo": int(sum(d.need_counts_l)) - d.need_counts_l[self.rank]}
+        if self.rp == 0 and self.pipe_stages:
+            out["pipeline_stages"] = self.pipe_stages
         if d.A is not None:
             chs = d.chunks[self.rs_chunks]
             out["reduce_all"] = (self.world - 1) * self.hp

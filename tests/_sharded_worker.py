@@ -24,11 +24,20 @@ class _OracleOp:
     def export_csr(self):
         return self.csr
 
-    def spmm(self, x, bias=None, x2=None):
+    def spmm(self, x, bias=None, x2=None, out=None, accumulate=False):
         if x2 is not None:
             x = torch.cat([x, x2])
         assert x.shape[0] == self.n_cols
-        return csr_oracle.csr_spmm(*self.csr, x.contiguous(), bias)
+        y = csr_oracle.csr_spmm(*self.csr, x.contiguous(), bias)
+        if accumulate:                       # GraphPlan.spmm(accumulate=True): added to `out` on the rows with entries
+            assert bias is None and out is not None
+            has = (self.csr[0][1:] > self.csr[0][:-1])
+            out[has] += y[has]
+            return out
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
 
 class OracleEngine:
@@ -94,6 +103,9 @@ def make_graph(kind):
         return synth.word_doc_graph(400, 4000, seed=12, n_classes=5), None
     if kind == "powerlaw_allhubs":    # sparse enough that a rank's rows reference only part of the other ranks' nodes
         g = synth.power_law_graph(900, 2400, seed=15, n_classes=5, features="sparse_identity")
+        return g, None
+    if kind == "powerlaw_big_allhubs":   # the GPU form of the same situation: long rows (segments) + F = 200, halo < operand
+        g = synth.power_law_graph(30000, 300000, seed=16, n_classes=5, features="sparse_identity")
         return g, None
     if kind in ("asym", "asym_keep_loops", "asym_raw"):
         g = synth.random_graph(300, 2500, seed=13, self_loops=7, duplicates=11)
@@ -602,6 +614,44 @@ def check_exchange_forms(sg, x_full, bias):
                         assert rel_err(got.cpu(), base.cpu()) < 1e-6, (form, K, transpose)
                     else:
                         assert torch.equal(got, base), (form, K, transpose, rel_err(got.cpu(), base.cpu()))
+        # graphs without hub structure: the pipelined exchange (own-column block at once, K stage blocks accumulated as
+        # their rows land) against the halo form -- the same entries, the blocks' partial sums added in another order
+        if sg.rp == 0:
+            kept = (sg.pipe_stages, sg.pipe_scheme)
+            for transpose in (False, True):
+                sg.exchange = "halo"
+                base = sg.spmm(x_l, bias, transpose=transpose).clone()
+                for K, scheme in ((1, "slices"), (2, "slices"), (5, "slices"), (0, "peer")):
+                    sg.set_pipeline(K, scheme)
+                    sg.exchange = "pipeline"
+                    got = sg.spmm(x_l, bias, transpose=transpose)
+                    assert rel_err(got.cpu(), base.cpu()) < 1e-6, (K, scheme, transpose, rel_err(got.cpu(), base.cpu()))
+                    assert torch.equal(got, sg.spmm(x_l, bias, transpose=transpose))      # run to run: the same bits
+                    d = sg.dirs[1 if (transpose and not sg.symmetric) else 0]
+                    pipe = sg._pipeline(d)
+                    assert len(pipe.stages) == (sg.world - 1 if scheme == "peer" else max(1, K))
+                    # every entry of B_r sits in exactly one block, every halo row travels in exactly one stage
+                    assert pipe.own_nnz + sum(st.nnz for st in pipe.stages) == d.B.export_csr()[1].numel()
+                    assert pipe.rows_received() == sum(d.need_counts_l) - d.need_counts_l[sg.rank]
+                    if scheme == "peer":
+                        for k, st in enumerate(pipe.stages):       # stage k: everything from rank - k - 1, nothing else
+                            src = (sg.rank - k - 1) % sg.world
+                            assert all(n == 0 for q, n in enumerate(st.recv_counts) if q != src)
+                            assert st.recv_counts[src] == d.need_counts_l[src]
+            sg.drop_unused_pipelines()
+            assert all(len(d.pipes) <= 1 for d in sg.dirs)
+            sg.set_pipeline(*kept)
+            try:
+                sg.exchange = "nonsense"
+                raise AssertionError("an unknown exchange form was accepted")
+            except ValueError:
+                pass
+        else:
+            try:
+                sg.exchange = "pipeline"
+                raise AssertionError("the pipelined exchange was accepted on a hub partition")
+            except ValueError:
+                pass
         # the halo lists prune: never more rows than the whole block, and the reduce side only rows A_r touches
         rows = sg.exchange_rows()
         assert rows["gather_halo"] <= rows["gather_all"]

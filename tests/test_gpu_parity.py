@@ -1913,6 +1913,74 @@ def test_split_operand_spmm(cuda, F):
         plan.spmm(x[:10], b, x2=x[:5])
 
 
+@pytest.mark.parametrize("F", [200, 256, 64, 96, 7, 260])   # full-wave, sub-group (16 / 32 lanes per row), scalar, two column tiles
+def test_accumulate_form_adds_the_rows_that_hold_entries_and_touches_no_other(cuda, F):
+    """tgcn_spmm_acc (GraphPlan.spmm(accumulate=True)): Y += M X on the rows with stored entries -- against the C CSR oracle
+    on the plan's own CSR (float64 accumulation) -- while rows WITHOUT entries keep their bits (they are neither read nor
+    written: the column blocks of the pipelined exchange each touch only their own rows).  Operators with short rows,
+    rows cut into segments, the dense hot block, many empty rows, a split operand; run to run the same bits; and the
+    sum of column-block launches equals the one-launch product."""
+    gen = torch.Generator().manual_seed(100 + F)
+    n, n_cols = 6000, 5000
+    # rows 0..39: long (segments / hot block); every third of the other rows: empty; the rest: 1..12 entries
+    rows, cols = [], []
+    for h in range(40):
+        c = torch.nonzero(torch.rand(n_cols, generator=gen) < 0.8 / (1 + 0.3 * h)).flatten()
+        rows.append(torch.full_like(c, h)); cols.append(c)
+    short = torch.arange(40, n)
+    short = short[short % 3 != 0]
+    deg = torch.randint(1, 13, (short.numel(),), generator=gen)
+    rows.append(torch.repeat_interleave(short, deg))
+    cols.append(torch.randint(0, n_cols, (int(deg.sum()),), generator=gen))
+    row, col = torch.cat(rows), torch.cat(cols)
+    val = torch.rand(row.numel(), generator=gen) - 0.3
+    plan = GraphPlan.from_coo(row.to(cuda), col.to(cuda), val.to(cuda), n, n_cols)
+    assert plan.query(_lib.Q_LONG_ROWS) > 0
+    rp, ci, v = (t.cpu() for t in plan.export_csr())
+    rp = rp.long()                                                   # (the C oracle takes int64 row pointers)
+    has = (rp[1:] > rp[:-1])
+    assert int((~has).sum()) > 1500
+    x = torch.randn(n_cols, F, generator=gen)
+    y0 = torch.randn(n, F, generator=gen)
+    xd = x.to(cuda)
+    y = y0.to(cuda).clone()
+    got = plan.spmm(xd, out=y, accumulate=True)
+    assert got.data_ptr() == y.data_ptr()
+    ref = y0.double() + csr_oracle.csr_spmm(rp, ci, v, x, None, acc64=True).double()
+    assert rel_err(y, ref) < TOL and row_rel_err(y[has.to(cuda)], ref[has]) < TOL
+    assert torch.equal(y.cpu()[~has], y0[~has])                      # untouched: the same bits
+    y2 = y0.to(cuda).clone()
+    plan.spmm(xd, out=y2, accumulate=True)
+    assert torch.equal(y2, y)                                        # reproducible
+    # the plain launch + the accumulate launch = twice the product (+ bias once)
+    b = torch.randn(F, generator=gen).to(cuda)
+    once = plan.spmm(xd, b)
+    twice = plan.spmm(xd, out=once.clone(), accumulate=True)
+    want = 2.0 * plan.spmm(xd).double() + b.double()
+    assert rel_err(twice, want) < TOL
+    # column blocks: M = [M_a | M_b] by column halves; plain(M_a) then acc(M_b) is the whole product
+    cut = n_cols // 2
+    lo = col < cut
+    pa = GraphPlan.from_coo(row[lo].to(cuda), col[lo].to(cuda), val[lo].to(cuda), n, cut)
+    pb = GraphPlan.from_coo(row[~lo].to(cuda), (col[~lo] - cut).to(cuda), val[~lo].to(cuda), n, n_cols - cut)
+    part = pa.spmm(xd[:cut].contiguous(), b)
+    pb.spmm(xd[cut:].contiguous(), out=part, accumulate=True)
+    assert rel_err(part, plan.spmm(xd, b)) < 2e-6
+    if F % 4 == 0:                                                   # split operand + strided result
+        hi = torch.randn(n_cols, F, device=cuda)
+        hi[9:9 + n_cols - 1234] = xd[1234:]
+        out = torch.full((n, F + 8), 3.0, device=cuda)
+        out[:, 4:4 + F] = y0.to(cuda)
+        plan.spmm(xd[:1234].clone(), out=out[:, 4:4 + F], x2=hi[9:9 + n_cols - 1234], accumulate=True)
+        assert rel_err(out[:, 4:4 + F], ref) < TOL and bool((out[:, :4] == 3).all()) and bool((out[:, 4 + F:] == 3).all())
+    with pytest.raises(ValueError):
+        plan.spmm(xd, accumulate=True)                               # nothing to add to
+    with pytest.raises(ValueError):
+        plan.spmm(xd, b, out=y, accumulate=True)                     # no bias in this form
+    for q in (plan, pa, pb):
+        q.close()
+
+
 def test_improved_gcnconv_fill_weight_two(cuda):
     """GCNConv(improved=True): added self loops weigh 2.0 (PyG gcn_norm `fill_value`); never used by
     the reference, supported for signature completeness."""

@@ -100,6 +100,21 @@ def test_world4_graph_without_hub_structure_true_halo(monkeypatch):
     run(4, ["powerlaw_allhubs"])
 
 
+def test_world4_pipelined_exchange_is_the_default_without_hubs(monkeypatch):
+    """hubs=None without TGCN_EXCHANGE: the pipelined exchange (own-column block at once, three stage blocks accumulated as
+    their rows land) through the exchange-form and the model-level checks (forward, backward, three Adam steps)."""
+    monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
+    monkeypatch.setenv("TGCN_PIPE_STAGES", "3")
+    run(4, ["powerlaw_allhubs", "asym"])
+
+
+def test_world8_pipelined_exchange_one_peer_per_stage(monkeypatch):
+    """The same with the per-peer scheme at the target rank count: stage k is the whole contribution of rank r - k - 1."""
+    monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
+    monkeypatch.setenv("TGCN_PIPE_SCHEME", "peer")
+    run(8, ["powerlaw_allhubs"])
+
+
 def test_world8_every_exchange_form(monkeypatch):
     """The rank count of the target node (8 GPUs, BASELINE.json configs c4 / c5), over gloo with the oracle engine: the
     hub partition with uneven shards and padding rows, all three exchange forms with one and three row chunks

@@ -115,6 +115,26 @@ def test_rccl_ranks_sharing_one_gpu(cuda, monkeypatch, world, exchange, chunks):
     run(world, ["wordoc_big", "wordoc_allhubs"] if world == 2 else ["wordoc_big"], "nccl")
 
 
+def test_two_gloo_ranks_on_one_gpu_pipelined_exchange_without_hubs(cuda, monkeypatch):
+    """hubs=None with the HIP engine: the pipelined exchange (the default there) -- own-column block at once, the stage blocks
+    added by `tgcn_spmm_acc` as their rows land -- against the oracle, against the halo form, through the sharded network
+    and the W1 update in the backward pass."""
+    monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
+    monkeypatch.setenv("TGCN_PIPE_STAGES", "3")
+    run(2, ["powerlaw_big_allhubs", "wordoc_allhubs"], "gloo")
+
+
+@pytest.mark.parametrize("world,stages,scheme", [(2, "2", "slices"), (4, "3", "slices"), (3, "", "peer")])
+def test_rccl_ranks_sharing_one_gpu_pipelined_exchange(cuda, monkeypatch, world, stages, scheme):
+    """The same over RCCL (ranks sharing cuda:0 over loopback sockets): K all_to_all_single calls with split sizes are
+    posted on the communicator's stream before the own-column block is launched, and every stage block waits for its own."""
+    _rccl_ranks_can_share_the_gpu()
+    monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
+    monkeypatch.setenv("TGCN_PIPE_STAGES", stages)
+    monkeypatch.setenv("TGCN_PIPE_SCHEME", scheme)
+    run(world, ["powerlaw_big_allhubs"], "nccl")
+
+
 def test_bench_two_ranks_as_a_plain_command(cuda):
     """`python3 bench.py --gpus 2 --config c2` with no launcher around it: two gloo ranks sharing cuda:0 rehearse the
     whole N > 1 bench (self-launch, graph broadcast, partition, exchange-form trial steps, timed region, sharded epoch)
