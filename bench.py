@@ -33,6 +33,7 @@ CONFIGS = {
     "c4": (2_000_000, 50_000_000, 200, 64),
     "c3": (1_000_000, 24_000_000, 200, 219),     # DBpedia-shaped: V = 30 k, 219 classes (l3)
     "c5": (8_000_000, 200_000_000, 256, 64),     # generic power law (no word / document structure), h = 256
+    "c5s": (1_000_000, 25_000_000, 256, 64),     # c5 at an eighth (NOT a BASELINE config: rehearsals of the hub-less N > 1 path)
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 FABRIC_GATHER_CEILING_GBPS = 8600.0   # MI355X_MICROARCH.md 'Indexed rows': random rows of an Infinity-Cache-resident table
@@ -302,7 +303,39 @@ def scaling_model(world, ms_per_step, parity, diag, sg, F):
     exchange = 2.0 * (ag + (rs if has_rs else 0.0))
     link_bytes = sg.hp * F * 4                       # what one rank sends to ONE peer in one collective (its own link)
     link_floor = 2.0 * (2 if has_rs else 1) * link_bytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+    pipe = diag.get("pipeline")
+    if pipe is not None:
+        # no hub structure, pipelined exchange: the step is the compute side (own-column block + accumulated stage blocks)
+        # plus whatever of the exchange side does not hide under it; the halo rows of a rank arrive over W - 1 links
+        comp = (pipe["compute_side_own_plus_stage_blocks"] or {}).get("max_ms")
+        exch = (pipe["exchange_side_packs_plus_stages"] or {}).get("max_ms")
+        whole = ms("whole_spmm_overlapped")
+        rows_in = sum(pipe["stage_rows_received"])
+        link_ms = rows_in * F * 4 / ((sg.world - 1) * XGMI_LINK_GBPS * 1e9) * 1e3
+        last_block = None
+        if comp is not None and pipe["stage_block_entries"]:
+            total = pipe["own_block_entries"] + sum(pipe["stage_block_entries"])
+            last_block = comp * pipe["stage_block_entries"][-1] / max(1, total)
+        return {
+            "single_device_ms_per_step": t1, "ms_per_step_measured": ms_per_step, "speedup_measured": t1 / ms_per_step,
+            "form": f"pipeline-{pipe['scheme']}/{pipe['stages']}",
+            "per_spmm_ms": {"compute_side_own_plus_stage_blocks": comp, "exchange_side_packs_plus_stages_alone": exch,
+                            "whole_overlapped": whole, "B_r_as_one_operator": b, "whole_operand_all_gather_alone": ag,
+                            "halo_gather_alone": ms("halo_gather_referenced_rows_only"),
+                            "exchange_at_link_peak": link_ms, "last_stage_block_estimate": last_block},
+            "exposed_exchange_ms_per_spmm": (whole - comp) if (whole is not None and comp is not None) else None,
+            "compute_scaling": t1 / (2.0 * comp) if comp else None,
+            "ms_per_step_if_exchange_fully_hidden": 2.0 * max(comp or 0.0, exch or 0.0),
+            "ms_per_step_if_exchange_fully_exposed": 2.0 * ((comp or 0.0) + (exch or 0.0)),
+            "ms_per_step_halo_form_exposed": 2.0 * ((b or 0.0) + (ms("halo_gather_referenced_rows_only") or 0.0)),
+            "link_GBps_assumed": XGMI_LINK_GBPS,
+            "note": "no hub structure: nothing but the rank's own-column block can run before operand rows arrive, so the "
+                    "halo rows travel in stages and each stage's column block is added (tgcn_spmm_acc) while the next "
+                    "stage is in flight; the exposed exchange is the first stage's head start minus the own block, plus "
+                    "whatever the links cannot deliver under the blocks (exposed_exchange_ms_per_spmm)"}
     return {
+        "per_spmm_ms": {"A_r": a, "B_r": b, "all_gather_alone": ag, "reduce_scatter_alone": rs if has_rs else None,
+                        "whole_overlapped": ms("whole_spmm_overlapped")},
         "single_device_ms_per_step": t1, "ms_per_step_measured": ms_per_step, "speedup_measured": t1 / ms_per_step,
         "compute_ms_per_step": compute, "compute_scaling": t1 / compute if compute else None,
         "exchange_ms_per_step_measured_alone": exchange,
@@ -841,6 +874,32 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10):
         sg._rows_scatter(xbuf, d0.need_cols, recv)
     out["halo_gather_referenced_rows_only"] = phase(halo_gather)
     out["rows_received_per_spmm"] = sg.exchange_rows()
+    if rp == 0 and sg.exchange == "pipeline":
+        # the pipelined exchange of a graph without hub structure, phase by phase: the compute side alone (own-column block
+        # + the stage blocks added in sequence, operands standing in), the exchange side alone (packs + the K all-to-all
+        # stages, nothing computed), and -- below, `whole_spmm_overlapped` -- the two together as `sg.spmm` runs them
+        pipe = sg._pipeline(d0)
+        bufs = [torch.randn(sum(st.recv_counts), F, device=dev, generator=gen) for st in pipe.stages]
+
+        def compute_side():
+            yy = pipe.own.spmm(x, None)
+            for st, b_ in zip(pipe.stages, bufs):
+                if st.op is not None:
+                    st.op.spmm(b_, out=yy, accumulate=True)
+
+        def exchange_side():
+            posted = []
+            for k, st in enumerate(pipe.stages):
+                pack = sg._rows_gather(x, st.send_slots)
+                posted.append(sg._all_to_all_v(pack, st.recv_counts, st.send_counts, direct, role=("diag", k)))
+            for _, work in posted:
+                work.wait()
+        out["pipeline"] = {"stages": len(pipe.stages), "scheme": pipe.scheme, "own_block_entries": pipe.own_nnz,
+                           "stage_block_entries": [st.nnz for st in pipe.stages],
+                           "stage_rows_received": [sum(st.recv_counts) for st in pipe.stages],
+                           "own_block": phase(lambda: pipe.own.spmm(x, None)),
+                           "compute_side_own_plus_stage_blocks": phase(compute_side),
+                           "exchange_side_packs_plus_stages": phase(exchange_side)}
     out["whole_spmm_overlapped"] = phase(lambda: sg.spmm(x, None))
 
     # HOST side of one distributed SpMM: the time the Python thread needs to ENQUEUE it (ctypes launches, the async
@@ -937,7 +996,7 @@ def main():
     gen_kw = dict(vocab_frac=0.03, doc_word_share=0.9) if args.config == "c3" else {}
 
     def make_graph(features):
-        if args.config == "c5":       # no word / document structure: every node is an ordinary node
+        if args.config in ("c5", "c5s"):  # no word / document structure: every node is an ordinary node
             return synth.power_law_graph(N, E, seed=44, device=dev, n_classes=C, features=features)
         return synth.word_doc_graph(N, E, seed=44, device=dev, n_classes=C, features=features, **gen_kw)
     if world == 1:
@@ -1040,48 +1099,75 @@ def main():
     exchange_selection = None
     if world > 1 and "TGCN_EXCHANGE" not in os.environ:
         # Which forms are tried.  Started by launch_ranks() (a parent with a wall budget and a fallback run watches):
-        # all of them.  Started directly under `python -m torch.distributed.run` there is nobody to fall back on if a
-        # pairwise / all-to-all form hangs on this node, and a lost run is worse than a slower exchange: RCCL's own
-        # collectives only (with A_r in 1 / 2 / 4 row chunks) unless TGCN_BENCH_TRY_ALL_FORMS=1 asks for the rest.
+        # all of them.  Started directly under `python -m torch.distributed.run` there is nobody to fall back on if the
+        # pairwise form (batched send / recv) hangs on this node, and a lost run is worse than a slower exchange: that
+        # form is left out unless TGCN_BENCH_TRY_ALL_FORMS=1 asks for it.
         watched = os.environ.get("TGCN_BENCH_WATCHDOG") == "1" or os.environ.get("TGCN_BENCH_TRY_ALL_FORMS") == "1"
-        forms = list(sg.EXCHANGES) if (watched or backend != "nccl") else ["collective"]
-        # "collective" first: RCCL's own collectives with A_r in one piece
-        chunkings = [1, 2, 4] if (sg.dirs[0].A is not None and "TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
-        trial = {}                                 # is the configuration the fallback of launch_ranks() runs, too
-        for K in chunkings:
-            sg.set_rs_chunks(K)
-            for mode in forms:
-                sg.exchange = mode
-                # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
-                # skipped.  A failure on ONE rank in the middle of a step leaves its peers inside a collective: they
-                # are released by the group's timeout (init_group), the process ends, and launch_ranks() runs the
-                # plain configuration in a fresh child -- nothing here tries to outwit a broken exchange.
-                ok = 1.0
-                ms = float("inf")
-                try:
+        # Unwatched: RCCL's own collectives and the forms built on all_to_all_single with split sizes (an ordinary RCCL
+        # collective, bounded by the group's timeout like the others): "halo", and for a graph without hub structure the
+        # pipelined exchange built on it.  The pairwise form (batched send / recv) stays with the watched launches.
+        forms = list(sg.EXCHANGES) if (watched or backend != "nccl") else ["collective", "halo"]
+        # candidates (form, A_r row chunks, pipeline stages, pipeline scheme); "collective" with A_r in one piece first:
+        # it is the configuration the fallback of launch_ranks() runs, too
+        candidates = []
+        if sg.rp > 0:
+            chunkings = [1, 2, 4] if ("TGCN_RS_CHUNKS" not in os.environ) else [sg.rs_chunks]
+            candidates = [(mode, K, 0, None) for K in chunkings for mode in forms]
+        else:
+            # no hub structure (c5): the whole-operand all-gather, the halo form, and the pipelined exchange with the
+            # stage count derived from the bytes, half of it, and one peer per stage
+            candidates = [(mode, 1, 0, None) for mode in forms if mode != "p2p" or watched]
+            auto_K = sg.pipe_stages
+            stage_counts = [auto_K] if "TGCN_PIPE_STAGES" in os.environ else sorted({auto_K, max(1, auto_K // 2), 1}, reverse=True)
+            candidates += [("pipeline", 1, K, "slices") for K in stage_counts]
+            if "TGCN_PIPE_SCHEME" not in os.environ and world > 2:
+                candidates.append(("pipeline", 1, 0, "peer"))
+            forms = forms + ["pipeline"]
+        trial = {}
+        for mode, K, stages, scheme in candidates:
+            if sg.rp > 0:
+                sg.set_rs_chunks(K)
+            if mode == "pipeline":
+                sg.set_pipeline(stages, scheme)
+            sg.exchange = mode
+            label = f"{mode}/{K}" if mode != "pipeline" else f"pipeline-{scheme}/{sg.pipe_stages if scheme == 'slices' else world - 1}"
+            # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
+            # skipped.  A failure on ONE rank in the middle of a step leaves its peers inside a collective: they
+            # are released by the group's timeout (init_group), the process ends, and launch_ranks() runs the
+            # plain configuration in a fresh child -- nothing here tries to outwit a broken exchange.
+            ok = 1.0
+            ms = float("inf")
+            try:
+                step()
+            except RuntimeError as e:
+                print(f"bench.py: exchange form {label} failed on rank {rank}: {e}"[:300], file=sys.stderr, flush=True)
+                ok = 0.0
+            flag = torch.tensor([ok], device=dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same branch
+            if flag.item() > 0:
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
                     step()
-                except RuntimeError as e:
-                    print(f"bench.py: exchange form {mode}/{K} failed on rank {rank}: {e}"[:300], file=sys.stderr, flush=True)
-                    ok = 0.0
-                flag = torch.tensor([ok], device=dev, dtype=torch.float64)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same branch
-                if flag.item() > 0:
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        step()
-                    barrier()
-                    ms = (time.perf_counter() - t0) / 3 * 1e3
-                t = torch.tensor([ms], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                trial[f"{mode}/{K}"] = t.item()
+                barrier()
+                ms = (time.perf_counter() - t0) / 3 * 1e3
+            t = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[label] = (t.item(), (mode, K, stages, scheme))
+        setting = {k: v[1] for k, v in trial.items()}
+        trial = {k: v[0] for k, v in trial.items()}
         best = min(trial, key=trial.get)
         if trial[best] == float("inf"):
             raise RuntimeError(f"no form of the exchange works on this node: {trial}")
         trial = {k: (v if v != float("inf") else None) for k, v in trial.items()}
-        sg.exchange = best.split("/")[0]
-        sg.set_rs_chunks(int(best.split("/")[1]))
-        sg.drop_unused_chunks()                    # the chunk operators of the counts that lost are dead weight
+        mode, K, stages, scheme = setting[best]
+        if sg.rp > 0:
+            sg.set_rs_chunks(K)
+        if mode == "pipeline":
+            sg.set_pipeline(stages, scheme)
+        sg.exchange = mode
+        sg.drop_unused_chunks()                    # the operators of the configurations that lost are dead weight
+        sg.drop_unused_pipelines()
         exchange_selection = {"ms_per_step": trial, "chosen": best, "rows_received_per_spmm": sg.exchange_rows(),
                               "forms_tried": forms, "watched_by_launcher": os.environ.get("TGCN_BENCH_WATCHDOG") == "1"}
         parallelism = (f"row{world}: " + ("hubs(words) replicated, hub rows reduce-scattered" if sg.rp > 0 else
@@ -1128,7 +1214,7 @@ def main():
     # ---- the headline, complete at this point; everything below is secondary ------------------------------------------
     secondary_errors = {}
     completed = {}                     # results of the secondary measurements that finished: an aborted record keeps them
-    workload = (f"{args.config}: synthetic {'power-law graph' if args.config == 'c5' else 'PMI/TF-IDF word-doc graph'}, N={N}, "
+    workload = (f"{args.config}: synthetic {'power-law graph' if args.config in ('c5', 'c5s') else 'PMI/TF-IDF word-doc graph'}, N={N}, "
                 f"E={E}, nnz={E + N} (with self loops), F={F}, seed 44; step = M@X+b and M^T@G; "
                 + ("normalisation mode 'reference' (PyG-1.6.3 gcn_norm's own fp32 arithmetic, weights bit for bit the "
                    "oracle's; M^T stored beside M)" if headline_mode == "reference" else

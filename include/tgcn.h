@@ -379,11 +379,19 @@ int tgcn_gemm_nt_colsum(const float *A, int64_t lda, const float *B, int64_t ldb
  * `sliding_window_tester` (:263-275).  Results are bit-identical to the reference: same uint32
  * counts, same edge order ((i,j),(j,i) interleaved, upper triangle row-major), same float32 PMI.
  *   X   int32 [n_docs, seq_len] row-major DEVICE pointer, tokens in [0, n_vocab), -1 = padding
+ * Memory: the reference keeps the counts in a dense V(V+1)/2 array (graphbuilder.pyx:44,134) and wraps its uint32 index
+ * beyond V = 65 535 (:250).  Here the dense triangle serves while it takes <= 16 GiB (V <= ~92 000); larger vocabularies
+ * take the SPARSE counter -- (i << 32 | j, count) records of bounded chunks of documents, sorted, summed by key and merged
+ * into one sorted list of distinct pairs: O(chunk + distinct pairs) memory, the same counts, edges, order and weights.
+ * Environment (read at create): TGCN_WW_COUNTER=dense|sparse pins the counter, TGCN_WW_CHUNK_PAIRS the records per chunk
+ * (default 2^27).  With the sparse counter the `cij` export builds the triangle on demand (small vocabularies only).
  * The handle owns its outputs (the reference leaks its malloc'd arrays, :65-66); export copies
  * them to host or device buffers (hipMemcpyDefault) and synchronises the stream.
  */
 typedef struct tgcn_wwedges tgcn_wwedges;
-enum { TGCN_WW_N_EDGES = 0, TGCN_WW_N_WINDOWS = 1, TGCN_WW_N_COUNTS = 2 /* n_vocab*(n_vocab+1)/2 */ };
+enum { TGCN_WW_N_EDGES = 0, TGCN_WW_N_WINDOWS = 1, TGCN_WW_N_COUNTS = 2 /* n_vocab*(n_vocab+1)/2 */,
+       TGCN_WW_SPARSE = 3 /* 1: the sorted-pair-list counter ran (large vocabularies), 0: the dense triangle */,
+       TGCN_WW_N_PAIRS = 4 /* distinct pairs i <= j with a count (sparse counter; -1 for the dense one) */ };
 int tgcn_wwedges_create(const int32_t *X, int64_t n_docs, int64_t seq_len, int64_t n_vocab,
                         int64_t window, int device, tgcn_stream stream, tgcn_wwedges **out);
 int tgcn_wwedges_query(const tgcn_wwedges *we, int what, int64_t *out);

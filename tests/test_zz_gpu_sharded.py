@@ -192,7 +192,38 @@ def test_bench_two_rccl_ranks_sharing_one_gpu_under_torch_distributed_run(cuda):
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), over RCCL."""
     rec = _bench_two_rccl_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                  "--master-addr", "127.0.0.1", "--master-port", str(free_port())])
-    assert rec["exchange_selection"]["chosen"].startswith("collective")
+    sel = rec["exchange_selection"]
+    # nobody watches this launch: RCCL's own collectives and the all_to_all_single forms are tried, the pairwise form is not
+    assert sel["forms_tried"] == ["collective", "halo"] and sel["watched_by_launcher"] is False
+    assert sel["chosen"].split("/")[0] in ("collective", "halo") and not any(k.startswith("p2p") for k in sel["ms_per_step"])
+
+
+def test_bench_two_rccl_ranks_without_hub_structure_try_the_pipelined_exchange(cuda):
+    """BASELINE config c5's situation at a rehearsal size (`--config c5s`: 1 M nodes / 25 M edges, power law, h = 256) under the
+    driver's launch line: no hub structure, so the trial steps time the whole-operand all-gather, the halo form and the
+    pipelined exchange, the record says which won, and `scaling_model` reports the pipeline's phases and what of the
+    exchange stayed exposed."""
+    import json
+    import subprocess
+    _rccl_ranks_can_share_the_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TGCN_BENCH_DEVICE="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--config", "c5s", "--steps", "3", "--warmup", "1", "--no-epoch"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    sel = rec["exchange_selection"]
+    assert "pipeline" in sel["forms_tried"] and any(k.startswith("pipeline-slices/") for k in sel["ms_per_step"]), sel
+    assert all(v is not None for v in sel["ms_per_step"].values()), sel          # every form ran
+    assert rec["distributed_parity"]["ok"] is True, rec["distributed_parity"]
+    if sel["chosen"].startswith("pipeline"):
+        sm = rec["scaling_model"]
+        assert sm["form"].startswith("pipeline-") and sm["per_spmm_ms"]["compute_side_own_plus_stage_blocks"] > 0
 
 
 def test_bench_rank_failing_alone_in_a_secondary_measurement_costs_neither_a_hang_nor_the_headline(cuda):
