@@ -57,11 +57,12 @@ if args.fused:
     from pytextgcn_amd.train import FlatLoop
     with FlatLoop(gcn, g, lr=lr) as loop:                              # :89 + :99-117
         for epoch in range(args.epochs):
-            loss, _, pred_val, pred_train = loop.epoch()
+            loss, val_loss, pred_val, pred_train = loop.epoch()        # (val_loss: :110, computed by the same fused pass)
             f1_val = f1_score(y_val, pred_val, average="macro")
             acc_train = accuracy_score(y_train, pred_train)
             if epoch % 10 == 0 or epoch == args.epochs - 1:
-                print(f"[{epoch + 1:3d}] loss: {loss: .3f}, training accuracy: {acc_train: .3f}, val_f1: {f1_val: .3f}")
+                print(f"[{epoch + 1:3d}] loss: {loss: .3f}, val_loss: {val_loss: .3f}, training accuracy: {acc_train: .3f}, "
+                      f"val_f1: {f1_val: .3f}")
 else:
     optimizer = th.optim.Adam(gcn.parameters(), lr=lr, amsgrad=True)   # :89
     for epoch in range(args.epochs):                                   # :99-117
@@ -74,12 +75,14 @@ else:
         gcn.eval()
         with th.no_grad():
             logits = gcn(g)
+            val_loss = criterion(logits[g.val_mask], g.y[g.val_mask])  # :110
             pred_val = np.argmax(logits[g.val_mask].cpu().numpy(), axis=1)
             pred_train = np.argmax(logits[g.train_mask].cpu().numpy(), axis=1)
             f1_val = f1_score(y_val, pred_val, average="macro")
             acc_train = accuracy_score(y_train, pred_train)
         if epoch % 10 == 0 or epoch == args.epochs - 1:
-            print(f"[{epoch + 1:3d}] loss: {loss.item(): .3f}, training accuracy: {acc_train: .3f}, val_f1: {f1_val: .3f}")
+            print(f"[{epoch + 1:3d}] loss: {loss.item(): .3f}, val_loss: {val_loss.item(): .3f}, training accuracy: "
+                  f"{acc_train: .3f}, val_f1: {f1_val: .3f}")
 th.cuda.synchronize()
 print(f"{args.epochs} epochs in {time.time() - t0:.2f} s")
 with th.no_grad():                                                     # :130-134

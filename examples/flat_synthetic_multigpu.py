@@ -96,11 +96,12 @@ if args.loop_object:
     t0 = time.time()
     with FlatLoop(gcn, y_l, train_l, val_l, optimizer=optimizer) as loop:
         for epoch in range(args.epochs):
-            loss_, _, pred_val, _ = loop.epoch()                      # global losses; class ids of this rank's rows
+            loss_, val_loss_, pred_val, _ = loop.epoch()              # global losses; class ids of this rank's rows
             hit = th.tensor([float((pred_val == y_l[val_l].cpu().numpy()).sum()), float(len(pred_val))], device=dev).double()
             dist.all_reduce(hit)
             if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
-                print(f"[{epoch + 1:3d}] loss: {loss_: .3f}, val accuracy: {(hit[0] / hit[1]).item(): .3f}", flush=True)
+                print(f"[{epoch + 1:3d}] loss: {loss_: .3f}, val_loss: {val_loss_: .3f}, val accuracy: "
+                      f"{(hit[0] / hit[1]).item(): .3f}", flush=True)
 else:
     # --rows: kept tensors (the restricted operators are cached under them); every rank passes a mask in the same call
     rows_train = train_l if args.rows else None
@@ -117,11 +118,13 @@ else:
         gcn.eval()
         with th.no_grad():
             logits = gcn(rows=rows_eval)
+            val_loss = sharded_cross_entropy(sg, logits, y_l, val_l)  # flat_amazon.py:110 (this rank's share of the mean)
             acc_val = accuracy(logits, val_l)
-        total = loss.detach().clone()
+        total = th.stack([loss.detach(), val_loss.detach()])
         dist.all_reduce(total)
         if rank == 0 and (epoch % 10 == 0 or epoch == args.epochs - 1):
-            print(f"[{epoch + 1:3d}] loss: {total.item(): .3f}, val accuracy: {acc_val: .3f}", flush=True)
+            print(f"[{epoch + 1:3d}] loss: {total[0].item(): .3f}, val_loss: {total[1].item(): .3f}, val accuracy: {acc_val: .3f}",
+                  flush=True)
 th.cuda.synchronize()
 with th.no_grad():
     acc_test = accuracy(gcn(), test_l)

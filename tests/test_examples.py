@@ -1,0 +1,72 @@
+"""The drop-in scripts run end to end (GPU): `examples/flat_synthetic.py` is the literal replay of the reference's training
+script (flat_amazon.py:60-134: corpus -> Text2GraphTransformer -> Data -> GCN(graph) -> CE on train_mask -> Adam(amsgrad) ->
+eval with val_loss and host-side metrics -> test metrics) on this package, `examples/flat_synthetic_multigpu.py` the same
+loop on the 1-D partition.  Each is started as a child process, as a user would start it."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPOCH = re.compile(r"\[\s*(\d+)\] loss:\s*([-\d.]+), val_loss:\s*([-\d.]+), (?:training accuracy:\s*([-\d.]+), val_f1|val accuracy):\s*([-\d.]+)")
+
+
+def _run(cmd, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=timeout)
+    out = res.stdout.decode()
+    assert res.returncode == 0, (out[-1500:], res.stderr.decode()[-3000:])
+    return out
+
+
+def _epochs(out):
+    rows = [m.groups() for m in map(EPOCH.search, out.splitlines()) if m]
+    assert len(rows) >= 3, out[-1500:]
+    return rows
+
+
+def test_flat_script_trains_in_both_forms_and_they_agree(cuda):
+    """`flat_synthetic.py --docs 2000 --epochs 30`, plain (torch's CE / Adam / dropout around the HIP operators: what the
+    import swap alone gives) and `--fused` (train.FlatLoop): both end, the loss falls, the training accuracy rises, a
+    validation loss is reported every epoch (flat_amazon.py:110), and the two forms reach the same test accuracy +- 1 %."""
+    accs = {}
+    for form in ([], ["--fused"]):
+        out = _run([sys.executable, os.path.join(ROOT, "examples", "flat_synthetic.py"), "--docs", "2000", "--epochs", "30"] + form)
+        rows = _epochs(out)
+        first, last = rows[0], rows[-1]
+        assert int(last[0]) == 30
+        assert float(last[1]) < 0.5 * float(first[1]), (first, last)            # training loss
+        assert float(last[2]) < float(first[2]), (first, last)                  # validation loss
+        assert float(last[3]) > float(first[3]) + 0.2 and float(last[3]) > 0.9, (first, last)   # training accuracy
+        m = re.search(r"Test Accuracy:\s*([\d.]+)\s+F1-Macro:\s*([\d.]+)", out)
+        assert m, out[-800:]
+        accs["fused" if form else "plain"] = float(m.group(1))
+        assert accs["fused" if form else "plain"] > 0.9
+    assert abs(accs["plain"] - accs["fused"]) <= 0.01 + 1e-9, accs
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("extra", [[], ["--loop-object", "--hidden", "200"]])
+def test_multi_gpu_script_under_gloo_world_2(cuda, extra):
+    """`flat_synthetic_multigpu.py` as two gloo ranks sharing the test box's GPU (the launch line of its docstring): the plain
+    loop and the loop object (W1's update inside the backward SpMM, activation reuse, rows=...)."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "examples", "flat_synthetic_multigpu.py"),
+                "--docs", "2000", "--epochs", "30", "--backend", "gloo", "--device", "0"] + extra, timeout=900)
+    rows = _epochs(out)
+    first, last = rows[0], rows[-1]
+    assert int(last[0]) == 30 and float(last[1]) < 0.5 * float(first[1]) and float(last[2]) < float(first[2]), (first, last)
+    assert float(last[4]) > float(first[4]) and float(last[4]) > 0.9, (first, last)          # validation accuracy
+    m = re.search(r"2 rank\(s\): 30 epochs in [\d.]+ s; test accuracy ([\d.]+)", out)
+    assert m and float(m.group(1)) > 0.9, out[-800:]
