@@ -776,6 +776,8 @@ def sharded_epoch_ms(sg, N, F, n_classes, dev, dist, reps=3, reuse=False, fuse_w
     # hub row is among them, so the last propagate step loses one collective each way (ShardedGraph.rows_view)
     rows_train = train_l if rows else None
     rows_eval = (train_l | val_l) if rows else None
+    if rows:
+        sg.prepare_rows(rows_train), sg.prepare_rows(rows_eval)     # collective, once: forward(rows=...) only looks them up
     pkg.enable_activation_reuse(reuse)
     # narrow: hub rows cross the links at the class width where the activation-free network allows (pytextgcn_amd/narrow.py).
     # Every variant starts from the same weights and draws the same KEYED dropout masks (a function of a node's place in

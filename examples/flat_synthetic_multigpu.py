@@ -106,6 +106,8 @@ else:
     # --rows: kept tensors (the restricted operators are cached under them); every rank passes a mask in the same call
     rows_train = train_l if args.rows else None
     rows_eval = (train_l | val_l) if args.rows else None
+    if args.rows:
+        sg.prepare_rows(rows_train), sg.prepare_rows(rows_eval)       # collective, once; the forward pass only looks them up
     th.cuda.synchronize()
     t0 = time.time()
     for epoch in range(args.epochs):

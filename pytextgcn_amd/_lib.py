@@ -125,6 +125,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)       # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    from .build import build_report
+    note = build_report().get("sources", {}).get("dense.hip", {}).get("pipe_kernel_isa_check", "")
+    if "skipped" in note:
+        import warnings
+        warnings.warn("pytextgcn_amd: " + note)
     got = lib.tgcn_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"libtgcn.so ABI version {got}, this package expects {ABI_VERSION}")

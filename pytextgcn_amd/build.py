@@ -68,6 +68,48 @@ def check_asm_ring_kernels(remarks: str) -> None:
                            + "\n  ".join(bad))
 
 
+# Kernels that may use scratch memory, with the reason.  Everything else in csrc/ must not (the build FAILS): a spill is a
+# silent 2-10 x on a kernel that was tuned to its register budget, and nothing else would report it.
+SCRATCH_ALLOWED = (
+    (re.compile(r"rocprim"), "rocPRIM's own kernels (one-sweep radix sort: per-lane digit arrays in private memory), "
+                             "one-off plan / graph construction, not on the per-step path"),
+)
+
+
+def resource_usage(remarks: str):
+    """[(kernel, scratch bytes per lane, VGPRs spilled, SGPRs spilled)] from hipcc -Rpass-analysis=kernel-resource-usage."""
+    out = []
+    for b in re.split(r"remark: Function Name: ", remarks)[1:]:
+        name = b.split()[0]
+        m = [re.search(pat, b) for pat in (r"ScratchSize \[bytes/lane\]: (\d+)", r"VGPRs Spill: (\d+)", r"SGPRs Spill: (\d+)")]
+        if m[0] is None or m[1] is None:
+            raise RuntimeError(f"build check: the kernel-resource-usage remark of {name} carries no "
+                               "'ScratchSize [bytes/lane]' / 'VGPRs Spill' field (has hipcc changed its wording?)")
+        out.append((name, int(m[0].group(1)), int(m[1].group(1)), int(m[2].group(1)) if m[2] else 0))
+    return out
+
+
+def check_no_spills(source: str, remarks: str) -> dict:
+    """Every kernel of `source`: no scratch memory, no spilled registers -- unless SCRATCH_ALLOWED names it.  Returns the
+    summary that goes into the build report; raises (the build fails) on a kernel that is not allow-listed."""
+    usage = resource_usage(remarks)
+    bad, allowed, sgpr_only = [], [], 0
+    for name, scratch, vspill, sspill in usage:
+        if not (scratch or vspill):
+            # SGPRs "spilled" with 0 bytes of scratch live in lanes of a spare VGPR (v_writelane / v_readlane): no memory
+            # traffic; counted in the report, not a failure
+            sgpr_only += 1 if sspill else 0
+            continue
+        line = f"{name}: scratch {scratch} B/lane, {vspill} VGPRs / {sspill} SGPRs spilled"
+        (allowed if any(pat.search(name) for pat, _ in SCRATCH_ALLOWED) else bad).append(line)
+    if bad:
+        raise RuntimeError(f"build check: kernels of {source} use scratch memory / spill registers (give the kernel a smaller "
+                           "register footprint or another occupancy target, or allow-list it in build.SCRATCH_ALLOWED with a "
+                           "reason):\n  " + "\n  ".join(bad))
+    return {"kernels": len(usage), "with_scratch": 0, "allow_listed_with_scratch": len(allowed),
+            "sgprs_parked_in_vgpr_lanes": sgpr_only}
+
+
 def scan_pipe_isa(disassembly: str):
     """(number of k_gemm_pipe functions, violations) in `llvm-objdump -d --no-show-raw-insn` output of the device code: a
     violation is an instruction that names a destination register of a `global_load_dwordx4` issued earlier in the same
@@ -108,8 +150,10 @@ def check_pipe_kernel_isa(obj: str) -> str:
     destination register of such a load between its issue and the `s_waitcnt vmcnt(0)` that covers it -- not a use, not a
     copy the register allocator slipped in.  The spill remarks cannot see a copy; the disassembly can.  The device code is
     taken out of the object (llvm-objdump --offloading) and every `k_gemm_pipe` function is scanned in program order (its
-    loop bodies are straight-line between the waits).  Returns a one-line summary; raises on a violation; says so and
-    returns when the ROCm binutils are not where expected (the check is then skipped, not failed)."""
+    loop bodies are straight-line between the waits).  Returns a one-line summary; raises on a violation.  When the ROCm
+    binutils are not where expected the summary starts with "k_gemm_pipe ISA check skipped": the caller (`build`) then does
+    NOT ship the unverified kernel -- it rebuilds dense.hip with -DTGCN_NT_PIPE=0 (the class-width nt product falls back on
+    k_gemm_tall, whose loads the compiler tracks) and says so loudly."""
     import glob
     import tempfile
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -152,32 +196,58 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(obj, [src] + HEADERS):
             tmp = obj + ".tmp%d" % os.getpid()
             cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", tmp]
-            if s == "dense.hip":
+            if s.endswith(".hip"):
                 cmd.append("-Rpass-analysis=kernel-resource-usage")
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             jobs.append((s, obj, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = []
+    report = _read_report()
     for s, obj, tmp, proc in jobs:
         out, _ = proc.communicate()
         if proc.returncode != 0:
             failed.append(f"{s}:\n{out}")
             if os.path.exists(tmp):
                 os.remove(tmp)
-        else:
+            continue
+        try:
+            if s.endswith(".hip"):
+                report[s] = check_no_spills(s, out)
             if s == "dense.hip":
-                try:
-                    check_asm_ring_kernels(out)
-                    note = check_pipe_kernel_isa(tmp)
-                    if verbose:
-                        print(note, file=sys.stderr)
-                except RuntimeError as e:
-                    failed.append(str(e))
-                    os.remove(tmp)
-                    continue
-            os.replace(tmp, obj)
+                check_asm_ring_kernels(out)
+                note = check_pipe_kernel_isa(tmp)
+                if note.startswith("k_gemm_pipe ISA check skipped"):
+                    # the kernel cannot be verified on this box: do not ship it
+                    import warnings
+                    msg = (f"pytextgcn_amd.build: {note}; dense.hip is rebuilt with -DTGCN_NT_PIPE=0 (the class-width nt "
+                           "product runs on k_gemm_tall instead of the unverified k_gemm_pipe)")
+                    warnings.warn(msg)
+                    print(msg, file=sys.stderr)
+                    res = subprocess.run([hipcc] + flags + ["-DTGCN_NT_PIPE=0", "-x", "hip", "-c", os.path.join(CSRC, s), "-o", tmp,
+                                          "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE,
+                                         stderr=subprocess.STDOUT, text=True)
+                    if res.returncode != 0:
+                        raise RuntimeError(f"{s} (-DTGCN_NT_PIPE=0):\n{res.stdout}")
+                    report[s] = check_no_spills(s, res.stdout)
+                    check_asm_ring_kernels(res.stdout)
+                    note += "; built with -DTGCN_NT_PIPE=0"
+                report[s]["pipe_kernel_isa_check"] = note
+                if verbose:
+                    print(note, file=sys.stderr)
+        except RuntimeError as e:
+            failed.append(str(e))
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            continue
+        os.replace(tmp, obj)
     if failed:
         raise RuntimeError("hipcc failed building libtgcn.so:\n" + "\n".join(failed))
+    n_k = sum(v.get("kernels", 0) for v in report.values())
+    n_allowed = sum(v.get("allow_listed_with_scratch", 0) for v in report.values())
+    report_line = (f"{n_k} kernels in {len(report)} sources, 0 kernels of csrc/ with scratch"
+                   + (f" ({n_allowed} library kernels of rocPRIM allow-listed)" if n_allowed else ""))
+    if verbose:
+        print("build check: " + report_line, file=sys.stderr)
     tmp = LIB_PATH + ".tmp%d" % os.getpid()
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
     if verbose:
@@ -188,7 +258,35 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.remove(tmp)
         raise RuntimeError("hipcc failed linking libtgcn.so:\n" + res.stdout)
     os.replace(tmp, LIB_PATH)
+    import json
+    with open(REPORT_PATH, "w") as f:
+        json.dump({"sources": report, "summary": report_line}, f, indent=1, sort_keys=True)
     return LIB_PATH
+
+
+REPORT_PATH = os.path.join(LIB_DIR, "build_report.json")
+
+
+def _read_report() -> dict:
+    """Per-source results of the last build's checks (a source that is not recompiled keeps its entry)."""
+    import json
+    try:
+        with open(REPORT_PATH) as f:
+            return dict(json.load(f).get("sources", {}))
+    except (OSError, ValueError):
+        return {}
+
+
+def build_report() -> dict:
+    """What the checks of the build that produced lib/libtgcn.so found: {"summary": "... 0 kernels with scratch ...",
+    "sources": {source: {"kernels", "with_scratch", "allow_listed_with_scratch"[, "pipe_kernel_isa_check"]}}}; empty when the
+    library was built by something else."""
+    import json
+    try:
+        with open(REPORT_PATH) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 if __name__ == "__main__":

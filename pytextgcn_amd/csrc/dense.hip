@@ -999,8 +999,15 @@ inline size_t tn_staged_lds_bytes(int k, int n) {
 // BITS (with DROP): the keep decisions come from the record the nn product left (Drop::bits) -- one 4-byte load and a few
 // bit tests per float4 instead of four hashes: the hash of an element is vector-ALU work that ADDS to the MFMA time on this
 // part (profiles/r04_pmc_dense.md), 0.18 ms of the 0.76 ms of the masked product at the c4 shapes.
+// Occupancy target: two workgroups per CU up to 7 accumulator tiles (k <= 224: 71 KB of LDS each).  With 8 tiles (k = 256,
+// c5's hidden width) the LDS image is 85 KB -- ONE workgroup per CU whatever the registers allow -- and the 128 accumulator
+// registers plus the staging registers do not fit the 256-register budget of the two-workgroup target (the masked
+// instantiation spilled 11 VGPRs, 48 B / lane of scratch): it is compiled for one workgroup per CU and takes what it needs.
+#ifndef TGCN_TN_STAGED8_WGS
+#define TGCN_TN_STAGED8_WGS 1         // 2: A/B builds with round 5's occupancy target (spills; tools/build_variant.py)
+#endif
 template <int NT, int MT, bool DROP, bool BITS = false>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_staged(const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, (MT >= 8 ? TGCN_TN_STAGED8_WGS : 2)) void k_gemm_tn_staged(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ G, int64_t ldg, int64_t N, int k,
                                                            int n, int64_t rows_per_wg, float *__restrict__ partial,
                                                            const Drop drop, const int k0) {

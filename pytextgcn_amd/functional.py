@@ -123,7 +123,7 @@ class _MaskedCE(torch.autograd.Function):
     def forward(ctx, logits: Tensor, target: Tensor, mask: Tensor, count, want_pred: bool):
         loss, grads, pred = _launch(logits.detach(), target, mask, ctx.needs_input_grad[0], count, want_pred)
         ctx.save_for_backward(*(grads if grads is not None else ()))
-        ctx.mask = mask
+        ctx.mask, ctx.mask_version = mask, mask._version      # (the zero-row note below is only true for THIS version)
         if not want_pred:
             return loss
         ctx.mark_non_differentiable(pred)
@@ -154,7 +154,10 @@ class _MaskedCE(torch.autograd.Function):
             note_colsum(dlogits, dbias)
         # every row the mask does not select is exactly zero (the kernel wrote 0.f there; scaling keeps it): the propagate
         # step that takes this gradient may skip those operand rows (plan.known_nonzero_rows)
-        note_zero_rows(base if base is not None else dlogits, ctx.mask)
+        # -- unless the caller edited the mask in place since the forward pass: the gradient's zero pattern is the OLD
+        # mask's, so no note is left and the consumer gathers every row
+        if ctx.mask._version == ctx.mask_version:
+            note_zero_rows(base if base is not None else dlogits, ctx.mask)
         return dlogits, None, None, None, None
 
 

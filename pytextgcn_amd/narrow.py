@@ -145,6 +145,12 @@ class NarrowGCN2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
+        if ctx.needs_input_grad[1] and ctx.fused_param is not None:
+            # a refusal ("second backward before step") must come BEFORE the first collective of this pass is started
+            from .sharded import _fused_optimizer_for
+            opt_ = _fused_optimizer_for(ctx.fused_param)
+            if opt_ is not None:
+                opt_.assert_no_pending_update(ctx.fused_param)
         sg = ctx.sg
         eng = sg.engine
         hp, rp, W = sg.hp, sg.rp, sg.world

@@ -100,6 +100,16 @@ class Adam(Optimizer):
         return True
 
     @torch.no_grad()
+    def assert_no_pending_update(self, p) -> None:
+        """Raises when `p` (registered with fuse_into_backward) already received its update of this step: a second backward
+        before step() would apply it twice.  The 1-D partition calls this BEFORE the backward pass starts its first
+        collective, so that a refusal never leaves peers inside one."""
+        st = self.state.get(p)
+        if st and st.get("fused_pending", False):
+            raise RuntimeError(
+                "pytextgcn_amd.optim.Adam: a parameter registered with fuse_into_backward() received a second backward "
+                "before step(): its update would be applied twice.")
+
     def _fused_update_sharded(self, p, sg, g, hub_block=None, pending=None) -> bool:
         """The same for a rank's row shard of W1 in the 1-D partition (pytextgcn_amd.sharded._ShardedPropagate): the
         regular rows are updated inside the backward SpMM (split operand), the hub slice by one Adam pass once its

@@ -51,7 +51,11 @@ def cluster_documents(edge_index: Tensor, edge_attr: Optional[Tensor], n_vocab: 
     score = torch.where(df[w] < max(2, D // 50), df[w], torch.zeros_like(df[w]))
     head = torch.zeros(D, dtype=torch.int64, device=dev).scatter_reduce_(0, d, score * V + w, "amax") % V
     lab = (head * 2654435761 % 1000003) % K
-    chunk = 1 << 22
+    # Memory: the D x K score matrix (4 D K bytes: 16 GB at D = 7.8 M documents and K = 512 -- choose `n_clusters` for the
+    # device) plus, per slab of edges, two [slab, K] temporaries (the gathered word rows and their product with the edge
+    # weights).  The slab is sized so that those two stay within `slab_bytes` (256 MB) whatever K is.
+    slab_bytes = 256 << 20
+    chunk = max(1 << 14, slab_bytes // (8 * K))
     for _ in range(max(1, int(iters))):
         ws = torch.zeros(V * K, device=dev).index_add_(0, w * K + lab[d], a).view(V, K)
         ws = ws / ws.sum(1, keepdim=True).clamp_min(1e-20)           # P(cluster | word)

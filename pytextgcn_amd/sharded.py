@@ -1273,43 +1273,48 @@ class ShardedGraph:
         return []
 
     # ---- the rows somebody reads (ShardedGCN.forward(rows=...)) ------------------------------------------------------
-    def rows_view(self, rows: Tensor) -> Optional["_RowsView"]:
-        """The local operators of a LAST propagate step whose result is read on `rows` only (a bool mask over this rank's
-        n_local rows): None unless NO rank reads a hub row -- in a TextGCN graph the hubs are the words and the rows
-        read are documents (flat_amazon.py:101,109-114), so the hub rows of the result need not exist at all:
+    def prepare_rows(self, rows: Tensor) -> Optional["_RowsView"]:
+        """COLLECTIVE: the local operators of a LAST propagate step whose result is read on `rows` only (a bool mask over this
+        rank's n_local rows that the caller keeps), built on every rank at the same time; None unless NO rank reads a hub
+        row -- in a TextGCN graph the hubs are the words and the rows read are documents (flat_amazon.py:101,109-114), so
+        the hub rows of the result need not exist at all:
 
             forward   y[rows] = B_r[rows, :] @ [gathered hubs ; own rows]      A_r and its reduce-scatter disappear;
             backward  g is zero outside `rows`, so its hub rows are:           nothing to gather;
                       d x[hubs] = RS(A'_r[:, rows] @ g_reg),  d x[regular] = B'_r[regular, rows] @ g_reg.
 
-        One collective of each propagate step and the entries of the unread rows go.  Built once per mask (kept with the
-        tensor, so its id cannot be recycled) and per chunk count.  COLLECTIVE on first use of a mask: the ranks agree
-        on whether any hub row is read (one all-reduce of a flag), so every rank must pass a mask in the same call or
-        none may."""
-        cache = self.__dict__.setdefault("_rows_views", {})
-        hit = cache.get(id(rows))
-        if hit is not None and hit[0] is rows and hit[1] == rows._version and hit[2] == self.rs_chunks:
-            return hit[3]
+        One collective of each propagate step and the entries of the unread rows go.  The ranks agree on whether any hub
+        row is read (one all-reduce of a flag) HERE, once per mask and chunk count; `ShardedGCN.forward(rows=mask)` then
+        only LOOKS the mask up (`rows_view`) -- which collectives a step contains never depends on a per-rank cache state.
+        `sharded.FlatLoop` prepares its two masks itself."""
         if rows.dtype != torch.bool or rows.dim() != 1 or rows.numel() != self.n_local:
             raise ValueError(f"rows must be a bool mask over this rank's {self.n_local} rows")
         if rows.device != self.real.device:
             raise ValueError("rows must live where the graph does")
+        cache = self.__dict__.setdefault("_rows_views", {})
         hp = self.hp
         no = torch.zeros(1, dtype=torch.float32, device=self._comm_device())
         if self.rp == 0 or bool((rows[:hp] & self.real[:hp]).any()):
             no += 1.0
         dist.all_reduce(no, op=dist.ReduceOp.MAX, group=self.group)
         view = None if float(no.item()) > 0.0 else _RowsView(self, rows[hp:] & self.real[hp:])
-        self._rows_views_built = getattr(self, "_rows_views_built", 0) + 1
-        if self._rows_views_built == 4:
-            import warnings
-            warnings.warn("ShardedGraph.rows_view: a fourth distinct `rows` mask -- the operators are built per mask TENSOR "
-                          "(one agreement among the ranks and three local operators each time); keep the masks and pass "
-                          "the same tensors every epoch", stacklevel=3)
-        if len(cache) >= 8:
-            cache.clear()
+        while len(cache) >= 16:                                # (oldest first: a mask in use is prepared again, collectively)
+            cache.pop(next(iter(cache)))
         cache[id(rows)] = (rows, rows._version, self.rs_chunks, view)
         return view
+
+    def rows_view(self, rows: Tensor) -> Optional["_RowsView"]:
+        """LOOKUP of what `prepare_rows(rows)` built (local, no collective).  A mask that was not prepared -- or was edited
+        in place, or prepared under another chunk count -- raises: preparing it here would enter a collective that peers
+        whose cache still holds it never reach."""
+        hit = self.__dict__.get("_rows_views", {}).get(id(rows))
+        if hit is not None and hit[0] is rows and hit[1] == rows._version and hit[2] == self.rs_chunks:
+            return hit[3]
+        if rows.dtype != torch.bool or rows.dim() != 1 or rows.numel() != self.n_local:
+            raise ValueError(f"rows must be a bool mask over this rank's {self.n_local} rows")
+        raise RuntimeError("ShardedGraph: this `rows` mask has not been prepared (or was edited in place / prepared under "
+                           "another TGCN_RS_CHUNKS since): call `sg.prepare_rows(mask)` on EVERY rank once (collective), keep "
+                           "the tensor and pass the same one every epoch")
 
     def exchange_rows(self) -> dict:
         """Rows per SpMM this rank receives in each form (what the halo lists prune), for reports."""
@@ -1370,6 +1375,8 @@ class _ShardedPropagate(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             p = getattr(ctx, "fused_param", None)
             opt = _fused_optimizer_for(p) if p is not None else None
+            if opt is not None:
+                opt.assert_no_pending_update(p)                # (before the first collective of this pass)
             # every rank takes the same branch: the registration and the shapes are the same on all of them
             if opt is None or not opt._fused_update_sharded(p, sg, g):
                 d_xw = sg.spmm(g, None, transpose=True)
@@ -1514,6 +1521,27 @@ class ShardedGCN(nn.Module):
             keep = sg.real.to(r.device)[r]                       # padding rows own nothing
             r, c, v = r[keep], c[keep], v[keep]
             self._h_ops = (sg.engine.make_op(r, c, v, sg.n_local, F_h), sg.engine.make_op(c, r, v, F_h, sg.n_local))
+        self.sync_replicated_parameters()
+
+    def sync_replicated_parameters(self) -> None:
+        """The replicated parameters (W2 ..., the hierarchy rows W1[N:]; the biases start at zero) are drawn from each rank's
+        own generator: make them the first rank's everywhere (COLLECTIVE; called by the constructor, and to be called again
+        after moving the module to its device if the ranks initialise them differently afterwards).  Loading a state dict
+        (`load_full_state_dict`) overwrites them anyway."""
+        sg = self.sg
+        if sg.group is None or sg.world == 1:
+            return
+        small = list(self.weights)[1:] + list(self.biases) + ([self.weight_h] if self.weight_h is not None else [])
+        flat = torch.cat([p.detach().reshape(-1) for p in small])
+        buf = flat.to(sg._comm_device()) if flat.device != sg._comm_device() else flat.clone()
+        dist.broadcast(buf, src=dist.get_global_rank(sg.group, 0), group=sg.group)
+        buf = buf.to(flat.device)
+        off = 0
+        with torch.no_grad():
+            for p in small:
+                n = p.numel()
+                p.copy_(buf[off:off + n].view_as(p))
+                off += n
 
     @classmethod
     def for_data(cls, sg: ShardedGraph, g, out_channels, **kw) -> "ShardedGCN":
@@ -1531,7 +1559,17 @@ class ShardedGCN(nn.Module):
         H = split_identity_block(x)
         if H is None:
             raise ValueError("g.x is wider than it is tall but its first N columns are not the identity")
-        return cls(sg, x.size(1), out_channels, hierarchy_feats=sg.scatter_rows(H.to_dense()).to_sparse(), **kw)
+        # this rank's rows of the block, selected on the sparse indices (the dense [N, F_h] block would be 4 GB at
+        # N = 2 M, F_h = 500): global row id -> local slot through the partition
+        Hc = H.coalesce()
+        (r, c), v = Hc.indices(), Hc.values()
+        p = sg.part
+        mine = p.owner.to(r.device)[r] == sg.rank
+        r, c, v = r[mine], c[mine], v[mine]
+        slot = p.slot.to(r.device)[r]
+        local = torch.where(p.hub_mask.to(r.device)[r], slot, sg.hp + slot)
+        feats = torch.sparse_coo_tensor(torch.stack([local, c]), v, (sg.n_local, H.size(1))).coalesce()
+        return cls(sg, x.size(1), out_channels, hierarchy_feats=feats, **kw)
 
     def load_full_state_dict(self, sd: dict) -> None:
         """From a single-device GCN state_dict (`layers.{i}.weight` / `.bias`, PyG-1.6.3 layout)."""
@@ -1575,7 +1613,8 @@ class ShardedGCN(nn.Module):
         `rows` (as in `GCN.forward`; a bool mask over the rank's n_local rows that the caller keeps): the rows of the
         result that will be READ.  When no rank reads a hub row (`ShardedGraph.rows_view`; the words of a TextGCN graph)
         the last propagate step runs without A_r and its reduce-scatter, its backward without the all-gather, and every
-        row outside `rows` holds the last bias.  Every rank passes a mask in the same call, or none does."""
+        row outside `rows` holds the last bias.  Every rank passes a mask in the same call, or none does, and the mask was
+        handed to `sg.prepare_rows(mask)` on every rank before (collective, once; `sharded.FlatLoop` does it itself)."""
         eng = self.sg.engine
         fused_drop = self.training and 0.0 < self.dropout < 1.0
         view = self.sg.rows_view(rows) if (rows is not None and len(self.weights) > 1) else None
@@ -1694,6 +1733,9 @@ class FlatLoop:
         conv.enable_activation_reuse(True)
         self.rows_train = train_local if needed_rows_only else None
         self.rows_eval = (train_local | val_local) if needed_rows_only else None
+        if needed_rows_only and len(model.weights) > 1:
+            for m in (self.rows_train, self.rows_eval):            # collective, once: forward(rows=...) only looks them up
+                self.sg.prepare_rows(m)
         self.epochs = 0
 
     def epoch(self):

@@ -293,6 +293,7 @@ def check_flat_loop(sg, g, N, dev=None, hidden=16, classes=8, narrow=False):
     if hasattr(ob, "fuse_into_backward"):
         ob.fuse_into_backward(b.weights[0])
     rows_eval = tr_l | va_l
+    sg.prepare_rows(tr_l), sg.prepare_rows(rows_eval)        # collective, once; forward(rows=...) only looks them up
     pkg.enable_activation_reuse(True)
     try:
         for step in range(3):
@@ -427,7 +428,8 @@ def check_rows_option(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, nar
             if fuse_w1:
                 o.fuse_into_backward(m.weights[0])
         models.append(m), opts.append(o)
-    view = sg.rows_view(m_l)                                 # (collective; also what forward(rows=m_l) will find)
+    view = sg.prepare_rows(m_l)                              # (collective; what forward(rows=m_l) will look up)
+    assert sg.rows_view(m_l) is view
     sharded.sharded_cross_entropy(sg, torch.zeros(sg.n_local, classes, device=dev), y_l, m_l)   # (the mask's row count: one all-reduce, once)
     assert view is not None and view.kept_entries["B"] < sg.dirs[0].B.export_csr()[1].numel()
     for step in range(steps):
@@ -471,6 +473,12 @@ def check_rows_option(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, nar
         m.eval()
     docs = sg.real.clone()
     docs[:sg.hp] = False
+    try:                                                     # a mask nobody prepared: refused locally, no collective entered
+        models[1](rows=docs)
+        raise AssertionError("an unprepared rows mask was accepted")
+    except RuntimeError as e:
+        assert "prepare_rows" in str(e)
+    sg.prepare_rows(docs)
     with torch.no_grad():
         full, part = models[1](), models[1](rows=docs)
     assert rel_err(part.cpu()[docs.cpu()], full.cpu()[docs.cpu()]) < 1e-5
@@ -480,8 +488,17 @@ def check_rows_option(sg, g, N, dev=None, dropout=0.0, hidden=16, classes=8, nar
     hubby = docs.clone()
     if dist.get_rank() == dist.get_world_size() - 1:
         hubby[0] = bool(sg.real[0])
+    assert sg.prepare_rows(hubby) is None
     with torch.no_grad():
         assert torch.equal(models[1](rows=hubby), full) and sg.rows_view(hubby) is None
+    docs_edit = docs.clone()
+    sg.prepare_rows(docs_edit)
+    docs_edit[sg.hp] = ~docs_edit[sg.hp]                     # edited in place since: the lookup refuses it
+    try:
+        sg.rows_view(docs_edit)
+        raise AssertionError("an edited rows mask was accepted")
+    except RuntimeError:
+        pass
     try:
         sg.rows_view(docs[:-1])
         raise AssertionError("a mask of the wrong length was accepted")

@@ -322,6 +322,36 @@ def test_build_refuses_spills_in_the_asm_ring_kernels():
         build.check_asm_ring_kernels(remark(ring, 0, 0).replace("ScratchSize [bytes/lane]", "Scratch bytes per lane"))
 
 
+def test_build_refuses_scratch_in_any_kernel_that_is_not_allow_listed():
+    """Every .hip source is compiled with -Rpass-analysis=kernel-resource-usage and `check_no_spills` fails the build on a
+    kernel with scratch memory or spilled VGPRs (round 5 shipped k_gemm_tn_staged<4, 8, true, true> with 11 spilled VGPRs and
+    nothing said so); rocPRIM's own kernels are allow-listed with a reason; SGPRs parked in VGPR lanes (0 bytes of scratch)
+    are counted, not refused.  The report of the build that produced the library says "0 kernels with scratch"."""
+    from pytextgcn_amd import build
+
+    def remark(name, scratch, vspill, sspill=0):
+        return (f"x.hip:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]\n"
+                f"remark:     VGPRs: 200 [-R]\nremark:     ScratchSize [bytes/lane]: {scratch} [-R]\n"
+                f"remark:     SGPRs Spill: {sspill} [-R]\nremark:     VGPRs Spill: {vspill} [-R]\n")
+    own = "_ZN4tgcn12_GLOBAL__N_116k_gemm_tn_stagedILi4ELi8ELb1ELb1EEEvPKf"
+    lib = "_ZN7rocprim17ROCPRIM_400200_NS6detail17trampoline_kernelINS1_34wrapped_radix_sort_onesweep"
+    ok = build.check_no_spills("x.hip", remark(own, 0, 0, 22) + remark(lib, 80, 0) + remark("k_plain", 0, 0))
+    assert ok == {"kernels": 3, "with_scratch": 0, "allow_listed_with_scratch": 1, "sgprs_parked_in_vgpr_lanes": 1}
+    with pytest.raises(RuntimeError, match="use scratch memory"):
+        build.check_no_spills("x.hip", remark(own, 48, 11))
+    with pytest.raises(RuntimeError, match="use scratch memory"):
+        build.check_no_spills("x.hip", remark("k_plain", 16, 0))
+    with pytest.raises(RuntimeError, match="carries no"):
+        build.check_no_spills("x.hip", remark(own, 0, 0).replace("VGPRs Spill", "Vector registers spilled"))
+    rep = build.build_report()
+    if rep:                                                            # this checkout's own build
+        assert "0 kernels of csrc/ with scratch" in rep["summary"], rep["summary"]
+        assert set(rep["sources"]) == {s for s in build.SOURCES if s.endswith(".hip")}
+        assert all(v["with_scratch"] == 0 for v in rep["sources"].values())
+        assert "no instruction touches" in rep["sources"]["dense.hip"]["pipe_kernel_isa_check"] \
+            or "TGCN_NT_PIPE=0" in rep["sources"]["dense.hip"]["pipe_kernel_isa_check"]
+
+
 def test_build_refuses_a_touched_ring_register_of_the_block_pipelined_kernel():
     """k_gemm_pipe keeps inline-asm loads in flight across a whole k-loop; the build scans its disassembly
     (pytextgcn_amd/build.py: scan_pipe_isa / check_pipe_kernel_isa) and fails if ANY instruction names a destination

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytextgcn_amd import dense  # noqa: E402
 
 N, h, C = 2_000_000, 200, 64
+if os.environ.get("AB_SHAPE"):               # AB_SHAPE=8000000,256,64: c5's layer shapes (N rows, hidden, classes)
+    N, h, C = (int(v) for v in os.environ["AB_SHAPE"].split(","))
 dev = "cuda:0"
 H = torch.randn(N, h, device=dev)
 W = torch.randn(h, C, device=dev)
@@ -42,7 +44,7 @@ for rnd in range(6):
             ev[i + 1].record()
         torch.cuda.synchronize()
         times[name] += [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
-print(os.environ.get("TGCN_LIB_PATH", "default library"))
+print(os.environ.get("TGCN_LIB_PATH", "default library"), f"N={N} h={h} C={C}")
 for name, ts in times.items():
     ts = sorted(ts[5:])          # first round = warm-up
     print(f"  {name:20s} median {ts[len(ts) // 2]:.3f} ms   min {ts[0]:.3f}")
