@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true", help="skip the epoch-time measurement")
+    p.add_argument("--epoch-matrix", action="store_true",
+                   help="also time the epoch under the switches one by one (`epoch_matrix` in the record); the default record "
+                        "carries the four figures the README quotes")
     p.add_argument("--no-verify", action="store_true",
                    help="N > 1: skip the comparison of the distributed SpMM pair with the single-device plan")
     p.add_argument("--cpu-sample-frac", type=float, default=1.0 / 32)
@@ -1307,45 +1310,67 @@ def main():
         parity = secondary("distributed_parity",                              # collective: every rank takes part
                            lambda: distributed_parity(sg, g, N, F, x, gout, bias, dev, dist, headline_mode))
 
-    epoch_ms = epoch_ms_fused = epoch_ms_reuse = epoch_ms_collapse = epoch_ms_w1 = epoch_ms_w1_reuse = epoch_ms_split = None
-    epoch_ms_narrow = epoch_ms_rows = epoch_ms_narrow_rows = epoch_ms_flat_loop = None
+    # The epoch of flat_amazon.py:99-117, four ways (the figures README / DESIGN quote):
+    #   epoch_ms                  the import swap alone: torch's loss / optimizer / dropout around the HIP operators (N = 1)
+    #   epoch_ms_fused            the package's fused loss, optimizer and dropout kernels
+    #   epoch_ms_fused_w1_update_in_backward_with_activation_reuse    + the two bitwise-neutral switches
+    #   epoch_ms_flat_loop        all five switches behind ONE object (train.FlatLoop / sharded.FlatLoop: + only the logits rows
+    #                             that are read; on the partition + the narrow exchange where the widths allow)
+    # `--epoch-matrix` adds the switches one by one (`epoch_matrix`).
+    epoch_ms = epoch_ms_fused = epoch_ms_w1_reuse = epoch_ms_flat_loop = None
+    epoch_matrix = None
     diagnostics = secondary("exchange_diagnostics", lambda: exchange_diagnostics(sg, F, dev, dist)) \
         if (world > 1 or force_sharded) else None
     if (world > 1 or force_sharded) and not args.no_epoch:
         del x, gout
+        narrow_ok = sg.rp > 0 and C % 4 == 0 and F % 4 == 0
         epoch_ms_fused = secondary("epoch_ms_fused", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist))
-        epoch_ms_reuse = secondary("epoch_ms_fused_with_activation_reuse",
-                                   lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True))
-        epoch_ms_w1 = secondary("epoch_ms_fused_w1_update_in_backward",
-                                lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True))
         epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
                                       lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True))
-        if sg.rp > 0 and C % 4 == 0 and F % 4 == 0:
-            epoch_ms_narrow = secondary("epoch_ms_fused_w1_reuse_narrow_exchange",
-                                        lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True))
         if sg.rp > 0:
-            epoch_ms_rows = secondary("epoch_ms_fused_w1_reuse_needed_rows_only",
-                                      lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, rows=True))
-            if C % 4 == 0 and F % 4 == 0:
-                epoch_ms_narrow_rows = secondary(
-                    "epoch_ms_fused_w1_reuse_narrow_exchange_needed_rows_only",
-                    lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True, rows=True))
+            epoch_ms_flat_loop = secondary(
+                "epoch_ms_flat_loop",
+                lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=narrow_ok, rows=True))
+        if args.epoch_matrix:
+            epoch_matrix = {
+                "fused_with_activation_reuse": secondary(
+                    "epoch_matrix.fused_with_activation_reuse", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True)),
+                "fused_w1_update_in_backward": secondary(
+                    "epoch_matrix.fused_w1_update_in_backward", lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, fuse_w1=True))}
+            if sg.rp > 0:
+                epoch_matrix["fused_w1_reuse_needed_rows_only"] = secondary(
+                    "epoch_matrix.fused_w1_reuse_needed_rows_only",
+                    lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, rows=True))
+            if narrow_ok:
+                epoch_matrix["fused_w1_reuse_narrow_exchange"] = secondary(
+                    "epoch_matrix.fused_w1_reuse_narrow_exchange",
+                    lambda: sharded_epoch_ms(sg, N, F, C, dev, dist, reuse=True, fuse_w1=True, narrow=True))
     if world == 1 and not args.no_epoch and not force_sharded:
         del x, gout
         epoch_ms = secondary("epoch_ms", lambda: epoch_time_ms(g, F, C, fused=False))
         epoch_ms_fused = secondary("epoch_ms_fused", lambda: epoch_time_ms(g, F, C, fused=True))
-        epoch_ms_reuse = secondary("epoch_ms_fused_with_activation_reuse", lambda: epoch_time_ms(g, F, C, fused=True, reuse=True))
-        epoch_ms_collapse = secondary("epoch_ms_fused_with_collapsed_eval",
-                                      lambda: epoch_time_ms(g, F, C, fused=True, collapse=True))
-        epoch_ms_w1 = secondary("epoch_ms_fused_w1_update_in_backward", lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True))
         # both switches are bitwise neutral
         epoch_ms_w1_reuse = secondary("epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
                                       lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True))
-        epoch_ms_rows = secondary("epoch_ms_fused_w1_reuse_needed_rows_only",
-                                  lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, needed_rows=True))
         epoch_ms_flat_loop = secondary("epoch_ms_flat_loop", lambda: flat_loop_epoch_ms(g, F, C))
-        epoch_ms_split = secondary("epoch_ms_fused_w1_reuse_split_bf16_gemms",
-                                   lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))
+        if args.epoch_matrix:
+            epoch_matrix = {
+                "fused_with_activation_reuse": secondary(
+                    "epoch_matrix.fused_with_activation_reuse", lambda: epoch_time_ms(g, F, C, fused=True, reuse=True)),
+                # pytextgcn_amd.enable_linear_collapse(): the eval forward of the activation-free network (models.py:22) as
+                # two propagations at the class width
+                "fused_with_collapsed_eval": secondary(
+                    "epoch_matrix.fused_with_collapsed_eval", lambda: epoch_time_ms(g, F, C, fused=True, collapse=True)),
+                "fused_w1_update_in_backward": secondary(
+                    "epoch_matrix.fused_w1_update_in_backward", lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True)),
+                # `gcn(g, rows=...)` written out by hand (train.FlatLoop does the same)
+                "fused_w1_reuse_needed_rows_only": secondary(
+                    "epoch_matrix.fused_w1_reuse_needed_rows_only",
+                    lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, needed_rows=True)),
+                # the layer-2 products in the opt-in split-bf16 mode (fp32-accurate, NOT bit-equal to the fp32 FMA chain)
+                "fused_w1_reuse_split_bf16_gemms": secondary(
+                    "epoch_matrix.fused_w1_reuse_split_bf16_gemms",
+                    lambda: epoch_time_ms(g, F, C, fused=True, fuse_w1=True, reuse=True, split_gemms=True))}
 
     model_of_scaling = scaling_model(world, elapsed / args.steps * 1e3, parity, diagnostics, sg, F) \
         if parallelism != "single" else None
@@ -1445,32 +1470,12 @@ def main():
             "plan": {"mode": headline_mode, "stores_transpose": not getattr(plan, "symmetric", False),
                      "device_bytes": plan.stats().get("device_bytes") if hasattr(plan, "stats") else None},
             "roofline": roofline,
+            # the epoch of flat_amazon.py:99-117 (NOT part of the metric), four ways -- see where they are measured above
             "epoch_ms": epoch_ms,
             "epoch_ms_fused": epoch_ms_fused,
-            # NOT part of the metric: the fused loop with pytextgcn_amd.enable_activation_reuse(), which
-            # hands the eval forward's layer-1 output (same W1, b1) to the next training forward
-            "epoch_ms_fused_with_activation_reuse": epoch_ms_reuse,
-            # NOT part of the metric either: pytextgcn_amd.enable_linear_collapse() evaluates the eval forward of
-            # the activation-free network (models.py:22) as two propagations at the class width
-            "epoch_ms_fused_with_collapsed_eval": epoch_ms_collapse,
-            # the fused loop with W1's Adam update applied inside the backward SpMM (optim.Adam.fuse_into_backward):
-            # every step of the epoch is still executed, bit for bit the same weights
-            "epoch_ms_fused_w1_update_in_backward": epoch_ms_w1,
             "epoch_ms_fused_w1_update_in_backward_with_activation_reuse": epoch_ms_w1_reuse,
-            # the same with the layer-2 products in the opt-in split-bf16 mode (dense.enable_split_gemms: fp32-accurate,
-            # NOT bit-equal to the fp32 FMA chain -- reported apart for that reason)
-            # opt-in, same results on every row the loop reads: `GCN.forward(g, rows=...)` -- the last layer computes only the
-            # logits rows that are consumed (training rows in the step; validation + training rows in evaluation); the word
-            # rows, two thirds of the operator's entries, are read by nobody.  NOT part of the metric
-            "epoch_ms_fused_w1_reuse_needed_rows_only": epoch_ms_rows,
-            # the same loop through the package's own object, pytextgcn_amd.train.FlatLoop(gcn, g, lr).epoch()
             "epoch_ms_flat_loop": epoch_ms_flat_loop,
-            "epoch_ms_fused_w1_reuse_split_bf16_gemms": epoch_ms_split,
-            # N > 1, opt-in, fp32-equal (1e-5) but not bit-equal to the plain exchange: ShardedGCN(narrow_exchange=True) --
-            # two of the four width-h collectives of a training step travel at the class width (pytextgcn_amd/narrow.py)
-            "epoch_ms_fused_w1_reuse_narrow_exchange": epoch_ms_narrow,
-            # N > 1, opt-in: both at once -- `ShardedGCN.forward(rows=...)` on the narrow exchange
-            "epoch_ms_fused_w1_reuse_narrow_exchange_needed_rows_only": epoch_ms_narrow_rows,
+            "epoch_matrix": epoch_matrix,                     # --epoch-matrix: the switches one by one
             # N > 1: the global training loss every variant of the sharded epoch reached after its timed epochs -- same
             # initial weights, same keyed dropout masks, so they must agree to fp32 rounding carried through Adam
             "sharded_epoch_final_loss": (dict(SHARDED_EPOCH_LOSS, max_rel_spread=(

@@ -384,10 +384,11 @@ class _Stage:
     """One stage of the pipelined exchange: the own slots that leave (`send_slots`, peers in rank order, `send_counts` rows
     each), the rows that arrive (`recv_counts`, rank order -- they form the stage's operand as they land, no scatter) and
     the block of B_r whose columns they are (`op`: [hp x sum(recv_counts)], None when it holds no entries)."""
-    __slots__ = ("send_slots", "send_counts", "recv_counts", "op", "nnz")
+    __slots__ = ("send_slots", "send_counts", "recv_counts", "op", "nnz", "rows")
 
-    def __init__(self, send_slots, send_counts, recv_counts, op, nnz):
+    def __init__(self, send_slots, send_counts, recv_counts, op, nnz, rows):
         self.send_slots, self.send_counts, self.recv_counts, self.op, self.nnz = send_slots, send_counts, recv_counts, op, nnz
+        self.rows = rows               # gathered-block row (owner * hp + slot) of every row of the receive buffer, in order
 
 
 class _Pipeline:
@@ -473,7 +474,9 @@ class _Pipeline:
             op = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, n_cols) if (nnz and n_cols) else None
             slots = d.send_slots[s_rem & (s_stage == k)].contiguous()      # peers in rank order, list order within a peer
             sg._check_list(slots, hp, "pipeline send slots")
-            self.stages.append(_Stage(slots, [int(v) for v in sc[k]], [int(v) for v in rc[k]], op, nnz))
+            lo = int(stage_start[k + 1])
+            self.stages.append(_Stage(slots, [int(v) for v in sc[k]], [int(v) for v in rc[k]], op, nnz,
+                                      need[order[lo:lo + n_cols]]))
 
     def rows_received(self) -> int:
         return int(sum(sum(st.recv_counts) for st in self.stages))

@@ -411,7 +411,29 @@ def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5
                 s, e = int(rp_l[i]), int(rp_l[i + 1])
                 want = (val_l[s:e].double().unsqueeze(1) * xg[col_l[s:e].to(cuda)].double().cpu()).sum(0)
                 assert rel_err(y[i], want.float()) < TOL, i
-        del x, xg, y
+        # the PIPELINED exchange's column blocks at this size (sharded._Pipeline; the default for hubs=None): the own-column
+        # block on the rank's own rows + the stage blocks ADDED (tgcn_spmm_acc) on the rows as they would land -- every row
+        # of the result against B_r as one operator (same entries; the blocks' partial sums associate differently), for the
+        # staged all-to-all (4 stages) and for one peer per stage (7 stages)
+        bias = torch.randn(F, device=cuda, generator=gen)
+        y_one = d.B.spmm(xg, bias)
+        x_own = xg[r * hp:(r + 1) * hp].contiguous()
+        for K, scheme in ((4, "slices"), (0, "peer")):
+            sg.set_pipeline(K, scheme)
+            pipe = sg._pipeline(d)
+            assert len(pipe.stages) == (4 if scheme == "slices" else W - 1)
+            assert pipe.own_nnz + sum(st.nnz for st in pipe.stages) == d.B.nnz
+            assert sum(int(st.rows.numel()) for st in pipe.stages) == foreign
+            y_p = pipe.own.spmm(x_own, bias)
+            for st in pipe.stages:
+                assert sum(st.recv_counts) == st.rows.numel() and bool(((st.rows // hp) != r).all())
+                st.op.spmm(xg[st.rows], out=y_p, accumulate=True)
+            e1, e2 = rel_err(y_p, y_one), row_rel_err(y_p, y_one)
+            _report(f"c5_pipeline_blocks_rank7_F{F}_{scheme}", max_norm=e1, row_relative=e2,
+                    stage_entries=[st.nnz for st in pipe.stages], own_entries=pipe.own_nnz)
+            assert e1 < 2e-6 and e2 < TOL, (F, scheme, e1, e2)
+            sg.drop_unused_pipelines()
+        del x, xg, y, y_one
     for dd in sg.dirs:
         dd.B.close()
     del sg, t_d, s_d, w_d, tgt, src, nw
