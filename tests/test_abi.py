@@ -44,6 +44,9 @@ def test_argument_errors_do_not_need_a_gpu():
     with pytest.raises(ValueError):
         _lib.check(st)
     assert lib.tgcn_spmm_workspace_bytes(None, 0, 8) == 0
+    # the accumulate form (ABI 6) shares tgcn_spmm's argument checks: a NULL plan is refused before anything is enqueued
+    assert lib.tgcn_spmm_acc(None, 0, None, 8, None, 0, 0, 8, None, 8, None, 0, None) == _lib.E_INVALID
+    assert b"NULL" in lib.tgcn_last_error()
     assert lib.tgcn_colsum_workspace_bytes(1000, 200) > 0
     assert lib.tgcn_plan_destroy(None) == 0
     q = ctypes.c_int64()

@@ -517,7 +517,7 @@ def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():
 
 
 def test_topical_generator_leaves_the_benchmark_graphs_alone_and_has_the_locality_it_claims():
-    """synth.word_doc_graph(..., n_topics=T): the corpus with topical locality of tools/exp_topical_order.py.  With
+    """synth.word_doc_graph(..., n_topics=T): the corpus with topical locality of round 5's document-order experiment (profiles/r05_exp_topical_order.log).  With
     n_topics = 0 (every BASELINE configuration) not one extra random number is drawn -- the seed-44 graphs keep the bytes
     they had in round 4 (fingerprint of a small instance) --; with topics the same graph comes out in both document orders
     (edge multiset up to the re-labelling, labels following their documents), documents of a topic are adjacent in the
