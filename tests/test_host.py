@@ -484,7 +484,11 @@ def test_committed_round5_bench_line_is_in_the_reference_mode_with_the_accurate_
     headline is the reference-order normalisation mode (the package default: PyG's own fp32 arithmetic, weights bit for
     bit the oracle's, M^T stored), `config` says so, and the accurate mode's figure of the same run stands beside it and
     shows that the modes cost the same."""
-    d = _check_frozen_roofline_contract("r05_bench_c4_n1.json", exact_committed_traffic=True)
+    d = _check_frozen_roofline_contract("r05_bench_c4_n1.json", exact_committed_traffic=False)
+    _check_reference_mode_headline(d)
+
+
+def _check_reference_mode_headline(d):
     assert d["config"]["normalisation_mode"] == "reference" and "reference" in d["config"]["workload"]
     assert d["plan"]["mode"] == "reference" and d["plan"]["stores_transpose"] is True
     acc = d["accurate_mode"]
@@ -492,6 +496,16 @@ def test_committed_round5_bench_line_is_in_the_reference_mode_with_the_accurate_
     assert acc["plan_device_bytes"] < 0.6 * d["plan"]["device_bytes"]                  # one stored block instead of two
     assert abs(d["value"] - acc["value"]) < 0.02 * d["value"]                           # the modes cost the same
     assert d["rccl"]["hsa_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_committed_round6_bench_line():
+    """profiles/r06_bench_c4_n1.json (final round-6 library; `traffic.json[c4_n1]` re-collected on it): the frozen roofline
+    contract on the counter figure as it stands, the reference-mode headline with the accurate mode beside it, and the epoch
+    reported four ways (the other switches moved behind `--epoch-matrix`)."""
+    d = _check_frozen_roofline_contract("r06_bench_c4_n1.json", exact_committed_traffic=True)
+    _check_reference_mode_headline(d)
+    assert d["epoch_ms_flat_loop"] < d["epoch_ms_fused_w1_update_in_backward_with_activation_reuse"] < d["epoch_ms_fused"]
+    assert d["epoch_matrix"] is None and "epoch_ms_fused_with_collapsed_eval" not in d
 
 
 def test_padded_row_buffers_are_recognised_only_as_they_were_handed_out():
