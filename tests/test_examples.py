@@ -70,3 +70,29 @@ def test_multi_gpu_script_under_gloo_world_2(cuda, extra):
     assert float(last[4]) > float(first[4]) and float(last[4]) > 0.9, (first, last)          # validation accuracy
     m = re.search(r"2 rank\(s\): 30 epochs in [\d.]+ s; test accuracy ([\d.]+)", out)
     assert m and float(m.group(1)) > 0.9, out[-800:]
+
+
+def test_bench_single_gpu_record_and_its_epoch_matrix(cuda):
+    """`python bench.py --config c2 --epoch-matrix` on the test box's GPU (no rocprofv3 child runs, no CPU leg): the contract
+    keys, the roofline object, the FOUR epoch figures a record carries and -- with the flag -- the switches one by one."""
+    import json
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "5", "--warmup", "2",
+                "--no-cpu-baseline", "--no-live-traffic", "--no-hbm-activity", "--epoch-matrix"], timeout=600)
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out[-1500:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["unit"] == "edges/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 2_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    four = [d[k] for k in ("epoch_ms", "epoch_ms_fused", "epoch_ms_fused_w1_update_in_backward_with_activation_reuse",
+                           "epoch_ms_flat_loop")]
+    assert all(isinstance(v, float) and v > 0 for v in four) and four[1] < four[0], four
+    m = d["epoch_matrix"]
+    assert set(m) == {"fused_with_activation_reuse", "fused_with_collapsed_eval", "fused_w1_update_in_backward",
+                      "fused_w1_reuse_needed_rows_only", "fused_w1_reuse_split_bf16_gemms"}
+    assert all(isinstance(v, float) and v > 0 for v in m.values()), m
+    assert d["secondary_errors"] is None
