@@ -1135,7 +1135,7 @@ def main():
             if mode == "pipeline":
                 sg.set_pipeline(stages, scheme)
             sg.exchange = mode
-            label = f"{mode}/{K}" if mode != "pipeline" else f"pipeline-{scheme}/{sg.pipe_stages if scheme == 'slices' else world - 1}"
+            label = f"{mode}/{K}" if mode != "pipeline" else f"pipeline-{scheme}/{world - 1 if scheme == 'peer' else sg.pipe_stages}"
             # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
             # skipped.  A failure on ONE rank in the middle of a step leaves its peers inside a collective: they
             # are released by the group's timeout (init_group), the process ends, and launch_ranks() runs the

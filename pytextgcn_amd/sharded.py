@@ -407,22 +407,23 @@ class _Pipeline:
     ACCUMULATE into the result of the own block (`GraphPlan.spmm(accumulate=True)` = `tgcn_spmm_acc`): rows without entries
     in a block are not touched, the order of the additions is the launch order -- deterministic.  Built from B_r's own CSR:
     same entries, same order within (row, block)."""
+    SCHEMES = ("slices", "peer")
 
     def __init__(self, sg: "ShardedGraph", d: _Direction, K: int, scheme: str):
         W, hp, r = sg.world, sg.hp, sg.rank
         if sg.rp != 0:
             raise ValueError("the pipelined exchange serves graphs without hub structure (hubs=None)")
-        if scheme not in ("slices", "peer"):
-            raise ValueError('pipeline scheme must be "slices" or "peer"')
+        if scheme not in self.SCHEMES:
+            raise ValueError(f"pipeline scheme must be one of {self.SCHEMES}")
         self.scheme = scheme
-        self.K = K = (W - 1 if scheme == "peer" else max(1, int(K)))
+        self.K = K = (W - 1 if scheme == "peer" else max(1, min(int(K), 16)))
         dev = d.need_cols.device
 
         def stage_of(owner, receiver, j, n):
-            """Stage of position j (of n) in the list of rows `receiver` reads from `owner` (tensors or ints; -1 = own)."""
+            """Stage of position j (of n) in the list of rows `receiver` reads from `owner` (tensors; -1 = own)."""
             if scheme == "peer":
                 return (receiver - owner) % W - 1
-            return (j * K) // n.clamp_min(1) if torch.is_tensor(n) else (j * K) // max(n, 1)
+            return (j * K) // n.clamp_min(1)
 
         # receive side: the rows this rank reads (need_cols, sorted: owner-major), their position in the owner's list
         need = d.need_cols
@@ -598,8 +599,8 @@ class ShardedGraph:
             K = int(per_peer * 1024 // (32 << 20))
         self.pipe_stages = max(1, min(int(K), self.PIPE_STAGES_MAX))
         self.pipe_scheme = scheme
-        if scheme not in ("slices", "peer"):
-            raise ValueError('pipeline scheme must be "slices" or "peer"')
+        if scheme not in _Pipeline.SCHEMES:
+            raise ValueError(f"pipeline scheme must be one of {_Pipeline.SCHEMES}")
 
     def _pipeline(self, d: _Direction) -> _Pipeline:
         key = (self.pipe_stages, self.pipe_scheme)

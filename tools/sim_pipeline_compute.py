@@ -89,9 +89,11 @@ for di, d in enumerate(sg.dirs[:1]):
                 return yy
             seq = timed(whole)
             Tx = out["T_x_ms_at_link_peak"]
-            per = Tx / max(1, len(pipe.stages))
-            model = max(own, per) + sum(max(b, per) for b in blocks[:-1]) + (blocks[-1] if blocks else 0.0)
-            # (stage 0 travels under the own block; stage k + 1 under block k; the last block has nothing left to hide)
+            rows_k = [sum(st.recv_counts) for st in pipe.stages]
+            pers = [Tx * rk / max(1, sum(rows_k)) for rk in rows_k]                  # a stage's share of the transfer
+            # stage 0 travels under the own block, stage k + 1 under block k; the last block has nothing left to hide
+            model = max(own, pers[0]) + sum(max(b, p_next) for b, p_next in zip(blocks[:-1], pers[1:])) + \
+                (blocks[-1] if blocks else 0.0)
             out[label] = {"stages": len(pipe.stages), "own_nnz": pipe.own_nnz, "stage_nnz": [st.nnz for st in pipe.stages],
                           "pack_ms": packs, "own_ms": own, "stage_block_ms": blocks, "sequence_ms": seq,
                           "step_ms_model_at_link_peak": round(model + packs, 3)}
