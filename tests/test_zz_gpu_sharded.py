@@ -36,7 +36,9 @@ def test_two_gloo_ranks_on_one_gpu_hub_partition(cuda):
 
 
 def test_single_rank_rccl_group(cuda):
-    run(1, ["wordoc_big"], "nccl")
+    """One RCCL rank: every collective degenerates; the hub-less graph runs the pipelined exchange with stages that carry no
+    rows (all_to_all_single with all-zero splits, stage blocks without entries)."""
+    run(1, ["wordoc_big", "wordoc_allhubs"], "nccl")
 
 
 def test_four_gloo_ranks_pairwise_exchange(cuda, monkeypatch):
