@@ -585,6 +585,8 @@ class ShardedGraph:
         -- a stage should still carry ~32 MB per peer at the hidden width (256 floats) so that the links run at their
         rate, at most PIPE_STAGES_MAX stages.  The blocks are cut on first use and kept per (K, scheme); local (the halo
         lists are agreed on already), but every rank must choose the same K and scheme."""
+        if scheme not in _Pipeline.SCHEMES:
+            raise ValueError(f"pipeline scheme must be one of {_Pipeline.SCHEMES}")
         if self.rp != 0:
             self.pipe_stages, self.pipe_scheme = 0, scheme
             return
@@ -599,8 +601,6 @@ class ShardedGraph:
             K = int(per_peer * 1024 // (32 << 20))
         self.pipe_stages = max(1, min(int(K), self.PIPE_STAGES_MAX))
         self.pipe_scheme = scheme
-        if scheme not in _Pipeline.SCHEMES:
-            raise ValueError(f"pipeline scheme must be one of {_Pipeline.SCHEMES}")
 
     def _pipeline(self, d: _Direction) -> _Pipeline:
         key = (self.pipe_stages, self.pipe_scheme)
