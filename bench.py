@@ -893,15 +893,15 @@ def exchange_diagnostics(sg, F, dev, dist, reps=10):
                     st.op.spmm(b_, out=yy, accumulate=True)
 
         def exchange_side():
-            posted = []
-            for k, st in enumerate(pipe.stages):
-                pack = sg._rows_gather(x, st.send_slots)
-                posted.append(sg._all_to_all_v(pack, st.recv_counts, st.send_counts, direct, role=("diag", k)))
-            for _, work in posted:
-                work.wait()
-        out["pipeline"] = {"stages": len(pipe.stages), "scheme": pipe.scheme, "own_block_entries": pipe.own_nnz,
+            posted = [sg._post_stage(pipe, k, x, "diag") for k in range(len(pipe.stages))]
+            for _, works in posted:
+                for w_ in works:
+                    w_.wait()
+        out["pipeline"] = {"stages": len(pipe.stages), "scheme": pipe.scheme + ("+prefix" if pipe.prefix else ""),
+                           "unpacked_prefix_rows_per_rank": pipe.prefix, "own_block_entries": pipe.own_nnz,
                            "stage_block_entries": [st.nnz for st in pipe.stages],
-                           "stage_rows_received": [sum(st.recv_counts) for st in pipe.stages],
+                           "stage_rows_received": [(sg.world - 1) * (st.span[1] - st.span[0]) if st.span is not None
+                                                   else sum(st.recv_counts) for st in pipe.stages],
                            "own_block": phase(lambda: pipe.own.spmm(x, None)),
                            "compute_side_own_plus_stage_blocks": phase(compute_side),
                            "exchange_side_packs_plus_stages": phase(exchange_side)}
@@ -1125,6 +1125,10 @@ def main():
             auto_K = sg.pipe_stages
             stage_counts = [auto_K] if "TGCN_PIPE_STAGES" in os.environ else sorted({auto_K, max(1, auto_K // 2), 1}, reverse=True)
             candidates += [("pipeline", 1, K, "slices") for K in stage_counts]
+            if "TGCN_PIPE_PREFIX" not in os.environ and (watched or backend != "nccl"):
+                # the degree-ordered slots nearly every peer reads travel unpacked, in K contiguous ranges (batched
+                # send / recv, like the pairwise form: with the watched launches)
+                candidates += [("pipeline", 1, K, "slices+prefix") for K in stage_counts if K > 1]
             if "TGCN_PIPE_SCHEME" not in os.environ and world > 2:
                 candidates.append(("pipeline", 1, 0, "peer"))
             forms = forms + ["pipeline"]
@@ -1132,8 +1136,9 @@ def main():
         for mode, K, stages, scheme in candidates:
             if sg.rp > 0:
                 sg.set_rs_chunks(K)
-            if mode == "pipeline":
-                sg.set_pipeline(stages, scheme)
+            if mode == "pipeline":                               # ("auto": one all-reduce -- every rank is here)
+                sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else
+                                (int(os.environ["TGCN_PIPE_PREFIX"]) if os.environ.get("TGCN_PIPE_PREFIX", "").isdigit() else 0))
             sg.exchange = mode
             label = f"{mode}/{K}" if mode != "pipeline" else f"pipeline-{scheme}/{world - 1 if scheme == 'peer' else sg.pipe_stages}"
             # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
@@ -1169,7 +1174,8 @@ def main():
         if sg.rp > 0:
             sg.set_rs_chunks(K)
         if mode == "pipeline":
-            sg.set_pipeline(stages, scheme)
+            sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else
+                            (int(os.environ["TGCN_PIPE_PREFIX"]) if os.environ.get("TGCN_PIPE_PREFIX", "").isdigit() else 0))
         sg.exchange = mode
         sg.drop_unused_chunks()                    # the operators of the configurations that lost are dead weight
         sg.drop_unused_pipelines()

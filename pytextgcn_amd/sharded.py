@@ -381,14 +381,20 @@ class _Direction:
 
 
 class _Stage:
-    """One stage of the pipelined exchange: the own slots that leave (`send_slots`, peers in rank order, `send_counts` rows
-    each), the rows that arrive (`recv_counts`, rank order -- they form the stage's operand as they land, no scatter) and
-    the block of B_r whose columns they are (`op`: [hp x sum(recv_counts)], None when it holds no entries)."""
-    __slots__ = ("send_slots", "send_counts", "recv_counts", "op", "nnz", "rows")
+    """One stage of the pipelined exchange and the block of B_r whose columns it brings.
+    packed stage (`span` is None): the own slots that leave (`send_slots`, peers in rank order, `send_counts` rows each) are
+        packed and travel by all_to_all_single; the rows that arrive (`recv_counts`, rank order) form the stage's operand
+        as they land -- no scatter;
+    unpacked stage (`span` = (lo, hi)): every peer is sent THE SAME contiguous slots x_local[lo:hi] (batched send / recv,
+        nothing packed); the operand is the [W * (hi - lo)] block of all ranks' slices (`recv_counts` = hi - lo per rank).
+    `op`: [hp x rows of the operand] (None when it holds no entries); `rows`: gathered-block row (owner * hp + slot) of
+    every operand row, in order."""
+    __slots__ = ("send_slots", "send_counts", "recv_counts", "op", "nnz", "rows", "span", "rows_read")
 
-    def __init__(self, send_slots, send_counts, recv_counts, op, nnz, rows):
+    def __init__(self, send_slots, send_counts, recv_counts, op, nnz, rows, span=None, rows_read=None):
         self.send_slots, self.send_counts, self.recv_counts, self.op, self.nnz = send_slots, send_counts, recv_counts, op, nnz
-        self.rows = rows               # gathered-block row (owner * hp + slot) of every row of the receive buffer, in order
+        self.rows, self.span = rows, span
+        self.rows_read = int(rows.numel()) if rows_read is None else rows_read      # operand rows B_r references
 
 
 class _Pipeline:
@@ -403,30 +409,43 @@ class _Pipeline:
                          on the xGMI mesh every pair of GPUs has its own link, so every link is busy in every stage;
         scheme "peer"    k = (rank - q) mod W - 1 : stage k is the whole contribution of ONE peer (W - 1 stages; rank r
                          sends to r + k + 1 while it receives from r - k - 1: a ring shift per stage, one link each way).
-    Both ends evaluate the same formula, so the lists need no further agreement beyond the halo lists.  The stage blocks
+    `prefix` = a > 0 (scheme "slices"; the same a on every rank): the rows of the first `a` slots of every rank -- slots are
+    dealt in DEGREE order, so these are the rows nearly every peer reads -- travel UNPACKED: slots [0, a) are cut into K
+    contiguous ranges, stage k sends x_local[a_k : a_k+1] as it stands to every peer (nothing is packed: the pack of the
+    rows to send is a third of the compute side at c5) and its operand is the [W * len_k] block of all ranks' ranges; ONE
+    packed stage then carries the referenced rows from slot a on.  A prefix row a peer does not read travels for nothing
+    (a is chosen so that >= 90 % of the (row, peer) pairs are read, `ShardedGraph.set_pipeline`).
+    Both ends evaluate the same formulas, so the lists need no further agreement beyond the halo lists.  The stage blocks
     ACCUMULATE into the result of the own block (`GraphPlan.spmm(accumulate=True)` = `tgcn_spmm_acc`): rows without entries
     in a block are not touched, the order of the additions is the launch order -- deterministic.  Built from B_r's own CSR:
     same entries, same order within (row, block)."""
     SCHEMES = ("slices", "peer")
 
-    def __init__(self, sg: "ShardedGraph", d: _Direction, K: int, scheme: str):
+    def __init__(self, sg: "ShardedGraph", d: _Direction, K: int, scheme: str, prefix: int = 0):
         W, hp, r = sg.world, sg.hp, sg.rank
         if sg.rp != 0:
             raise ValueError("the pipelined exchange serves graphs without hub structure (hubs=None)")
         if scheme not in self.SCHEMES:
             raise ValueError(f"pipeline scheme must be one of {self.SCHEMES}")
-        self.scheme = scheme
+        self.scheme, self.world = scheme, W
         self.K = K = (W - 1 if scheme == "peer" else max(1, min(int(K), 16)))
+        self.prefix = a = max(0, min(int(prefix), hp)) if scheme == "slices" else 0
+        n_pre = K if a > 0 else 0                          # unpacked stages: the prefix in K slot ranges
+        Kt = 1 if a > 0 else K                             # packed stages (with a prefix: one, for the rows from slot a on)
+        bounds = [a * k // K for k in range(K + 1)] if a > 0 else [0]
         dev = d.need_cols.device
 
         def stage_of(owner, receiver, j, n):
-            """Stage of position j (of n) in the list of rows `receiver` reads from `owner` (tensors; -1 = own)."""
+            """Packed stage of position j (of n) in the list of rows `receiver` reads from `owner` (tensors)."""
             if scheme == "peer":
                 return (receiver - owner) % W - 1
-            return (j * K) // n.clamp_min(1)
+            return (j * Kt) // n.clamp_min(1)
 
-        # receive side: the rows this rank reads (need_cols, sorted: owner-major), their position in the owner's list
-        need = d.need_cols
+        # receive side: the rows this rank reads (need_cols, sorted: owner-major) -- without the prefix rows, which arrive
+        # unpacked --, their position in the owner's list
+        need_all = d.need_cols
+        in_prefix = ((need_all // hp) != r) & ((need_all % hp) < a)
+        need = need_all[~in_prefix]
         n_owner = need // hp
         counts = torch.bincount(n_owner, minlength=W)
         starts = torch.cumsum(counts, 0) - counts
@@ -436,51 +455,75 @@ class _Pipeline:
         # column of the stage's receive buffer a needed row lands in: rank order, then list order (all_to_all_single)
         key = (n_stage + 1) * (W * hp) + need                         # (stage, owner, slot): `need` is already owner-major
         order = torch.argsort(key, stable=True)
-        per_stage = torch.bincount(n_stage[order] + 1, minlength=K + 1)
+        per_stage = torch.bincount(n_stage[order] + 1, minlength=Kt + 1)
         stage_start = torch.cumsum(per_stage, 0) - per_stage
         landing = torch.empty_like(need)
         landing[order] = torch.arange(need.numel(), device=dev) - stage_start[n_stage[order] + 1]
-        # gathered-block row -> (stage, landing column); own rows: the slot itself (operand = x_local in place)
+        # gathered-block row -> (stage, operand row).  Stage ids: -1 own (operand = x_local in place: the slot itself),
+        # 0 .. n_pre - 1 the unpacked prefix ranges (owner * len_k + slot - a_k), n_pre .. the packed stages
         col_stage = torch.full((W * hp,), -2, dtype=torch.int64, device=dev)
         col_land = torch.zeros(W * hp, dtype=torch.int64, device=dev)
-        col_stage[need] = n_stage
+        col_stage[need] = torch.where(n_stage >= 0, n_stage + n_pre, n_stage)
         col_land[need] = torch.where(n_owner == r, need - r * hp, landing)
-        recv_counts = torch.zeros(K, W, dtype=torch.int64, device=dev)
+        pre_read = []
+        if a > 0:
+            pre = need_all[in_prefix]
+            p_owner, p_slot = pre // hp, pre % hp
+            bt = torch.tensor(bounds, dtype=torch.int64, device=dev)
+            p_k = torch.searchsorted(bt, p_slot, right=True) - 1      # range k holds slots [bounds[k], bounds[k + 1])
+            col_stage[pre] = p_k
+            col_land[pre] = p_owner * (bt[p_k + 1] - bt[p_k]) + (p_slot - bt[p_k])
+            pre_read = torch.bincount(p_k, minlength=K).tolist()
+        recv_counts = torch.zeros(Kt, W, dtype=torch.int64, device=dev)
         rem = n_owner != r
         recv_counts.index_put_((n_stage[rem], n_owner[rem]), torch.ones_like(need[rem]), accumulate=True)
-        # send side: my slots every peer reads (send_slots, peers in rank order), cut by the SAME formula
-        s_peer = torch.repeat_interleave(torch.arange(W, device=dev), d.send_counts.to(dev))
-        s_starts = torch.cumsum(d.send_counts.to(dev), 0) - d.send_counts.to(dev)
+        # send side: my slots every peer reads (send_slots, peers in rank order; the prefix slots leave unpacked), cut by
+        # the SAME formula
+        s_peer_all = torch.repeat_interleave(torch.arange(W, device=dev), d.send_counts.to(dev))
+        s_keep = (s_peer_all == r) | (d.send_slots >= a)
+        s_peer, s_slots = s_peer_all[s_keep], d.send_slots[s_keep]
+        s_counts = torch.bincount(s_peer, minlength=W)
+        s_starts = torch.cumsum(s_counts, 0) - s_counts
         s_pos = torch.arange(s_peer.numel(), device=dev) - s_starts[s_peer]
-        s_stage = stage_of(r, s_peer, s_pos, d.send_counts.to(dev)[s_peer])
+        s_stage = stage_of(r, s_peer, s_pos, s_counts[s_peer])
         s_rem = s_peer != r
-        send_counts = torch.zeros(K, W, dtype=torch.int64, device=dev)
+        send_counts = torch.zeros(Kt, W, dtype=torch.int64, device=dev)
         send_counts.index_put_((s_stage[s_rem], s_peer[s_rem]), torch.ones_like(s_peer[s_rem]), accumulate=True)
         # the blocks, from B_r's own CSR
         rowptr, col, val = d.B.export_csr()
         row = torch.repeat_interleave(torch.arange(hp, device=col.device), (rowptr[1:] - rowptr[:-1]).long())
         col = col.long()
         e_stage, e_col = col_stage[col], col_land[col]
-        if bool((e_stage < -1).any()):
+        if bool((e_stage == -2).any()):
             raise RuntimeError("sharded: B_r references a column outside its own need list")
         sel = e_stage == -1
         self.own = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, hp)
         self.own_nnz = int(sel.sum())
         rc, sc = recv_counts.tolist(), send_counts.tolist()
         self.stages = []
-        for k in range(K):
+        ar_w = torch.arange(W, device=dev)
+        for k in range(n_pre):                             # unpacked: the prefix range k of every rank
+            lo, hi = bounds[k], bounds[k + 1]
+            n_k = hi - lo
             sel = e_stage == k
+            nnz = int(sel.sum())
+            op = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, W * n_k) if (nnz and n_k) else None
+            rows = (ar_w.unsqueeze(1) * hp + torch.arange(lo, hi, device=dev).unsqueeze(0)).reshape(-1)
+            self.stages.append(_Stage(None, None, [n_k] * W, op, nnz, rows, span=(lo, hi), rows_read=int(pre_read[k])))
+        for k in range(Kt):                                # packed
+            sel = e_stage == n_pre + k
             nnz = int(sel.sum())
             n_cols = int(sum(rc[k]))
             op = sg.engine.make_op(row[sel], e_col[sel], val[sel], hp, n_cols) if (nnz and n_cols) else None
-            slots = d.send_slots[s_rem & (s_stage == k)].contiguous()      # peers in rank order, list order within a peer
+            slots = s_slots[s_rem & (s_stage == k)].contiguous()           # peers in rank order, list order within a peer
             sg._check_list(slots, hp, "pipeline send slots")
             lo = int(stage_start[k + 1])
             self.stages.append(_Stage(slots, [int(v) for v in sc[k]], [int(v) for v in rc[k]], op, nnz,
                                       need[order[lo:lo + n_cols]]))
 
     def rows_received(self) -> int:
-        return int(sum(sum(st.recv_counts) for st in self.stages))
+        """Rows that arrive per SpMM: the other ranks' prefix ranges (read or not) + the packed stages' rows."""
+        return (self.world - 1) * self.prefix + int(sum(sum(st.recv_counts) for st in self.stages if st.span is None))
 
 
 class _RowsView:
@@ -561,7 +604,9 @@ class ShardedGraph:
         import os
         self._build_halo_lists()
         self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
-        self.set_pipeline(os.environ.get("TGCN_PIPE_STAGES"), os.environ.get("TGCN_PIPE_SCHEME", "slices"))
+        self.pipe_prefix = 0
+        self.set_pipeline(os.environ.get("TGCN_PIPE_STAGES"), os.environ.get("TGCN_PIPE_SCHEME", "slices"),
+                          prefix=os.environ.get("TGCN_PIPE_PREFIX", "0"))
         # a graph without hub structure has nothing to cover a whole-operand all-gather with: only the referenced rows
         # travel, pipelined under the column blocks; a hub partition overlaps its two collectives with A_r / B_r
         self.exchange = os.environ.get("TGCN_EXCHANGE", "pipeline" if self.rp == 0 else "collective")
@@ -580,16 +625,26 @@ class ShardedGraph:
             raise ValueError(f"the exchange form must be one of {self.EXCHANGES + ('pipeline',)}, got {form!r}")
         self._exchange = form
 
-    def set_pipeline(self, K=None, scheme: str = "slices") -> None:
+    PIPE_PREFIX_READ_SHARE = 0.9       # the unpacked prefix reaches as far as this share of its (row, peer) pairs is read
+
+    def set_pipeline(self, K=None, scheme: str = "slices", prefix=None) -> None:
         """Number of stages and scheme of the pipelined exchange (`_Pipeline`; hub-less graphs).  K = None: from the bytes
         -- a stage should still carry ~32 MB per peer at the hidden width (256 floats) so that the links run at their
-        rate, at most PIPE_STAGES_MAX stages.  The blocks are cut on first use and kept per (K, scheme); local (the halo
-        lists are agreed on already), but every rank must choose the same K and scheme."""
+        rate, at most PIPE_STAGES_MAX stages.  `prefix`: rows per rank that are sent to every peer UNPACKED, ahead of the
+        stages (0 = none; None = keep the current choice; "auto" = the longest prefix of the degree-ordered slots of
+        which the peers read >= PIPE_PREFIX_READ_SHARE of the (row, peer) pairs, the smallest such over the ranks).  The
+        blocks are cut on first use and kept per (K, scheme, prefix); local once the numbers are fixed (the halo lists are
+        agreed on already), but every rank must choose the same ones -- K = None and prefix = "auto" agree through one
+        all-reduce each (collective)."""
         if scheme not in _Pipeline.SCHEMES:
             raise ValueError(f"pipeline scheme must be one of {_Pipeline.SCHEMES}")
         if self.rp != 0:
-            self.pipe_stages, self.pipe_scheme = 0, scheme
+            self.pipe_stages, self.pipe_scheme, self.pipe_prefix = 0, scheme, 0
             return
+        if prefix == "auto":
+            prefix = self._auto_prefix()
+        if prefix is not None:
+            self.pipe_prefix = max(0, min(int(prefix), self.hp))
         if K is None or K == "":
             d = self.dirs[0]
             own = d.need_counts_l[self.rank] if d.need_counts_l is not None else 0
@@ -602,8 +657,31 @@ class ShardedGraph:
         self.pipe_stages = max(1, min(int(K), self.PIPE_STAGES_MAX))
         self.pipe_scheme = scheme
 
+    def _auto_prefix(self) -> int:
+        """The longest prefix [0, a) of this rank's (degree-ordered) slots of which the peers read at least
+        PIPE_PREFIX_READ_SHARE of the (slot, peer) pairs, over both directions; the minimum over the ranks (collective when
+        there is a group); a multiple of 256 rows; 0 when it would cover less than 1 / 64 of the shard."""
+        W, hp, r = self.world, self.hp, self.rank
+        if W < 2:
+            return 0
+        a = hp
+        for d in self.dirs:
+            if d.send_slots is None:
+                return 0
+            peer = torch.repeat_interleave(torch.arange(W, device=d.send_slots.device), d.send_counts.to(d.send_slots.device))
+            pop = torch.bincount(d.send_slots[peer != r], minlength=hp).double()      # peers that read slot s
+            share = torch.cumsum(pop, 0) / ((W - 1) * torch.arange(1, hp + 1, device=pop.device, dtype=torch.float64))
+            ok = torch.nonzero(share >= self.PIPE_PREFIX_READ_SHARE).flatten()
+            a = min(a, int(ok[-1]) + 1 if ok.numel() else 0)
+        if self.group is not None:
+            t = torch.tensor([float(a)], device=self._comm_device())
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            a = int(t.item())
+        a -= a % 256
+        return a if a * 64 >= hp else 0
+
     def _pipeline(self, d: _Direction) -> _Pipeline:
-        key = (self.pipe_stages, self.pipe_scheme)
+        key = (self.pipe_stages, self.pipe_scheme, self.pipe_prefix)
         pipe = d.pipes.get(key)
         if pipe is None:
             if d.send_slots is None:
@@ -613,7 +691,7 @@ class ShardedGraph:
 
     def drop_unused_pipelines(self) -> None:
         """Release the column blocks of every (K, scheme) but the current one (bench.py times a few)."""
-        keep = (self.pipe_stages, self.pipe_scheme)
+        keep = (self.pipe_stages, self.pipe_scheme, self.pipe_prefix)
         for d in self.dirs:
             for key in [k for k in d.pipes if k != keep]:
                 pipe = d.pipes.pop(key)
@@ -638,7 +716,7 @@ class ShardedGraph:
         self._setup(edge_index, edge_weight, num_nodes, int(world), int(rank), hubs, add_self_loops, normalize, engine,
                     symmetric, degree_sum)
         self._exchange = "collective"
-        self.pipe_stages, self.pipe_scheme = 0, "slices"
+        self.pipe_stages, self.pipe_scheme, self.pipe_prefix = 0, "slices", 0
         if halo_lists:
             self._build_halo_lists_offline(edge_index)
             self.set_pipeline(None)
@@ -1026,7 +1104,7 @@ class ShardedGraph:
         else:
             y.index_copy_(0, idx, x)
 
-    def _recv_buffer(self, role, shape, dtype, device) -> Tensor:
+    def _recv_buffer(self, role, shape, dtype, device, zero: bool = False) -> Tensor:
         """Receive buffer of one collective of the distributed SpMM, kept per (role, shape): `role` names the collective
         inside one SpMM (the gather, the reduce of chunk k), so two transfers in flight never share one; consecutive
         SpMMs reuse it in stream order (the consumer of call n is enqueued before the collective of call n + 1, and the
@@ -1036,7 +1114,9 @@ class ShardedGraph:
         if buf is None:
             if len(self._recv) >= 64:
                 self._recv.clear()
-            buf = torch.empty(shape, dtype=dtype, device=device)
+            # `zero`: a buffer part of which no transfer ever writes (the own range of an unpacked pipeline stage) must
+            # still hold finite values: the dense hot block of an operator multiplies EVERY operand row by a weight
+            buf = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
             self._recv[key] = buf
         return buf
 
@@ -1133,22 +1213,37 @@ class ShardedGraph:
         return y
 
     def _spmm_pipeline(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor]) -> Tensor:
-        """The distributed SpMM of a graph without hub structure: every stage's rows are packed and its all-to-all posted
-        up front (the communicator's stream runs them one after the other beside the compute stream), the own-column block
-        starts at once, and block k is added as soon as stage k has landed."""
+        """The distributed SpMM of a graph without hub structure: every stage's transfer is posted up front, in order (the
+        communicator's stream runs them one after the other beside the compute stream) -- an unpacked stage sends its
+        range of x_local as it stands, a packed one packs its rows first --, the own-column block starts at once, and block
+        k is added as soon as stage k has landed."""
         pipe = self._pipeline(d)
-        direct = self._stream_ordered(x_local)
-        key = self.dirs.index(d)
-        posted = []
-        for k, st in enumerate(pipe.stages):
-            pack = self._rows_gather(x_local, st.send_slots)
-            posted.append(self._all_to_all_v(pack, st.recv_counts, st.send_counts, direct, role=("pipe", key, pipe.K, k)))
+        posted = [self._post_stage(pipe, k, x_local, ("pipe", self.dirs.index(d))) for k in range(len(pipe.stages))]
         y = pipe.own.spmm(x_local, bias)                       # overlaps the first stage
-        for st, (recv, work) in zip(pipe.stages, posted):
-            work.wait()
+        for st, (recv, works) in zip(pipe.stages, posted):
+            for w_ in works:
+                w_.wait()
             if st.op is not None:
                 st.op.spmm(recv, out=y, accumulate=True)       # overlaps the next stage
         return y
+
+    def _post_stage(self, pipe: _Pipeline, k: int, x_local: Tensor, tag) -> Tuple[Tensor, list]:
+        """Start the transfer of stage k of `pipe`: (the stage's operand buffer, the works to wait for)."""
+        st = pipe.stages[k]
+        direct = self._stream_ordered(x_local)
+        role = (tag, pipe.K, pipe.prefix, k)
+        if st.span is None:
+            pack = self._rows_gather(x_local, st.send_slots)
+            recv, work = self._all_to_all_v(pack, st.recv_counts, st.send_counts, direct, role=role)
+            return recv, [work]
+        lo, hi = st.span
+        buf = self._recv_buffer(role, (self.world * (hi - lo), x_local.size(1)), x_local.dtype, x_local.device, zero=True)
+        works = []
+        if self.world > 1 and hi > lo:
+            piece = x_local[lo:hi]                          # (the own range is not copied: no block reads it)
+            works = self._all_gather_p2p(buf, piece, hi - lo, own=False) if direct else \
+                self._all_gather_p2p_staged(buf, piece, hi - lo)
+        return buf, works
 
     def _apply_B(self, d: _Direction, x_local: Tensor, bias: Optional[Tensor], xbuf: Tensor, whole: Optional[Tensor]) -> Tensor:
         if whole is not None:
@@ -1240,27 +1335,29 @@ class ShardedGraph:
                 finish(y_hub)
             adam(slice(0, hp), y_hub, None, None, None)
 
-    def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor):
-        """All-gather as W - 1 direct sends and receives per rank, batched into one group call.  Only for
-        transfers the backend orders on the stream (`_stream_ordered`)."""
-        hp = self.hp
+    def _all_gather_p2p(self, xbuf: Tensor, shard: Tensor, n: Optional[int] = None, own: bool = True):
+        """All-gather as W - 1 direct sends and receives per rank, batched into one group call (`n` rows per rank, default
+        the whole shard: every peer is sent THE SAME source rows, nothing is packed).  Only for transfers the backend
+        orders on the stream (`_stream_ordered`)."""
+        hp = self.hp if n is None else n
         ranks = dist.get_process_group_ranks(self.group)
         ops = []
         for q in range(self.world):
             if q != self.rank:
                 ops.append(dist.P2POp(dist.isend, shard, ranks[q], group=self.group))
                 ops.append(dist.P2POp(dist.irecv, xbuf[q * hp:(q + 1) * hp], ranks[q], group=self.group))
-        xbuf[self.rank * hp:(self.rank + 1) * hp].copy_(shard)
+        if own:
+            xbuf[self.rank * hp:(self.rank + 1) * hp].copy_(shard)
         return dist.batch_isend_irecv(ops) if ops else []
 
-    def _all_gather_p2p_staged(self, xbuf: Tensor, shard: Tensor):
+    def _all_gather_p2p_staged(self, xbuf: Tensor, shard: Tensor, n: Optional[int] = None):
         """The same exchange for device tensors over a host-serviced backend: the shard goes to pinned
         host memory with a BLOCKING copy (ordered after the kernel that produced it), the transfers run
         host to host, and the gathered block returns with a blocking host-to-device copy (ordered before
         the SpMM that reads it, and visible to it: the copy engine, not a host store through the PCIe
         BAR, writes the rows).  No overlap with the local SpMM -- this form only serves rehearsals of
         the N > 1 code path on boxes without RCCL peers."""
-        hp, W = self.hp, self.world
+        hp, W = (self.hp if n is None else n), self.world
         ranks = dist.get_process_group_ranks(self.group)
         send = self._host_stage("ag_send", shard.shape, shard.dtype)
         recv = self._host_stage("ag_recv", xbuf.shape, xbuf.dtype)

@@ -634,30 +634,47 @@ def check_exchange_forms(sg, x_full, bias):
         # graphs without hub structure: the pipelined exchange (own-column block at once, K stage blocks accumulated as
         # their rows land) against the halo form -- the same entries, the blocks' partial sums added in another order
         if sg.rp == 0:
-            kept = (sg.pipe_stages, sg.pipe_scheme)
+            kept = (sg.pipe_stages, sg.pipe_scheme, sg.pipe_prefix)
             for transpose in (False, True):
                 sg.exchange = "halo"
                 base = sg.spmm(x_l, bias, transpose=transpose).clone()
-                for K, scheme in ((1, "slices"), (2, "slices"), (5, "slices"), (0, "peer")):
-                    sg.set_pipeline(K, scheme)
+                auto_a = None
+                for K, scheme, prefix in ((1, "slices", 0), (2, "slices", 0), (5, "slices", 0), (0, "peer", 0),
+                                          (2, "slices", 37), (3, "slices", "auto"), (2, "slices", sg.hp), (0, "peer", sg.hp)):
+                    sg.set_pipeline(K, scheme, prefix=prefix)       # ("auto": one all-reduce -- every rank is here)
+                    if prefix == "auto":
+                        auto_a = sg.pipe_prefix
+                        assert 0 <= auto_a <= sg.hp and auto_a % 256 == 0
                     sg.exchange = "pipeline"
                     got = sg.spmm(x_l, bias, transpose=transpose)
                     assert rel_err(got.cpu(), base.cpu()) < 1e-6, (K, scheme, transpose, rel_err(got.cpu(), base.cpu()))
                     assert torch.equal(got, sg.spmm(x_l, bias, transpose=transpose))      # run to run: the same bits
                     d = sg.dirs[1 if (transpose and not sg.symmetric) else 0]
                     pipe = sg._pipeline(d)
-                    assert len(pipe.stages) == (sg.world - 1 if scheme == "peer" else max(1, K))
-                    # every entry of B_r sits in exactly one block, every halo row travels in exactly one stage
+                    unpacked = [st for st in pipe.stages if st.span is not None]
+                    packed = [st for st in pipe.stages if st.span is None]
+                    want_a = 0 if scheme == "peer" else (min(prefix, sg.hp) if prefix != "auto" else auto_a)
+                    assert pipe.prefix == want_a and (scheme == "peer" or sg.pipe_prefix == want_a)
+                    assert len(packed) == (sg.world - 1 if scheme == "peer" else (1 if want_a else max(1, K)))
+                    assert len(unpacked) == (max(1, K) if want_a else 0)
+                    # every entry of B_r sits in exactly one block; every halo row arrives exactly once -- in an unpacked
+                    # range of the prefix (where unread rows travel too) or in one packed stage
                     assert pipe.own_nnz + sum(st.nnz for st in pipe.stages) == d.B.export_csr()[1].numel()
-                    assert pipe.rows_received() == sum(d.need_counts_l) - d.need_counts_l[sg.rank]
-                    if scheme == "peer":
+                    halo = sum(d.need_counts_l) - d.need_counts_l[sg.rank]
+                    assert sum(st.rows_read for st in unpacked) + sum(sum(st.recv_counts) for st in packed) == halo
+                    assert pipe.rows_received() == (sg.world - 1) * pipe.prefix + sum(sum(st.recv_counts) for st in packed)
+                    assert [st.span for st in unpacked] == [(want_a * k // max(1, K), want_a * (k + 1) // max(1, K))
+                                                            for k in range(len(unpacked))]
+                    if want_a == sg.hp:                              # everything travels unpacked: the packed stage is empty
+                        assert all(sum(st.recv_counts) == 0 and st.op is None for st in packed)
+                    if scheme == "peer" and prefix == 0:
                         for k, st in enumerate(pipe.stages):       # stage k: everything from rank - k - 1, nothing else
                             src = (sg.rank - k - 1) % sg.world
                             assert all(n == 0 for q, n in enumerate(st.recv_counts) if q != src)
                             assert st.recv_counts[src] == d.need_counts_l[src]
             sg.drop_unused_pipelines()
             assert all(len(d.pipes) <= 1 for d in sg.dirs)
-            sg.set_pipeline(*kept)
+            sg.set_pipeline(*kept[:2], prefix=kept[2])
             try:
                 sg.exchange = "nonsense"
                 raise AssertionError("an unknown exchange form was accepted")

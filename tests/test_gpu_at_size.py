@@ -418,20 +418,28 @@ def test_config_c5_eight_rank_partition_without_hubs_and_its_halo_lists(cuda, c5
         bias = torch.randn(F, device=cuda, generator=gen)
         y_one = d.B.spmm(xg, bias)
         x_own = xg[r * hp:(r + 1) * hp].contiguous()
-        for K, scheme in ((4, "slices"), (0, "peer")):
-            sg.set_pipeline(K, scheme)
+        # ... and with the unpacked prefix ("auto": the degree-ordered slots of which >= 90 % of the (row, peer) pairs are read
+        # travel as 4 contiguous ranges, one packed stage for the rest)
+        for K, scheme, prefix in ((4, "slices", 0), (0, "peer", 0), (4, "slices", "auto")):
+            sg.set_pipeline(K, scheme, prefix=prefix)
             pipe = sg._pipeline(d)
-            assert len(pipe.stages) == (4 if scheme == "slices" else W - 1)
+            tag = scheme + ("+prefix" if prefix else "")
+            assert len(pipe.stages) == (W - 1 if scheme == "peer" else (5 if prefix else 4))
             assert pipe.own_nnz + sum(st.nnz for st in pipe.stages) == d.B.nnz
-            assert sum(int(st.rows.numel()) for st in pipe.stages) == foreign
+            assert sum(st.rows_read for st in pipe.stages) == foreign          # every halo row arrives exactly once
+            if prefix:
+                assert 0.2 * hp < pipe.prefix < 0.8 * hp and pipe.prefix % 256 == 0
+                read = sum(st.rows_read for st in pipe.stages if st.span is not None)
+                assert read >= 0.88 * (W - 1) * pipe.prefix                    # >= 90 % of the prefix pairs (here: rank 7's)
             y_p = pipe.own.spmm(x_own, bias)
             for st in pipe.stages:
-                assert sum(st.recv_counts) == st.rows.numel() and bool(((st.rows // hp) != r).all())
+                assert sum(st.recv_counts) == st.rows.numel()
+                assert st.span is not None or bool(((st.rows // hp) != r).all())
                 st.op.spmm(xg[st.rows], out=y_p, accumulate=True)
             e1, e2 = rel_err(y_p, y_one), row_rel_err(y_p, y_one)
-            _report(f"c5_pipeline_blocks_rank7_F{F}_{scheme}", max_norm=e1, row_relative=e2,
+            _report(f"c5_pipeline_blocks_rank7_F{F}_{tag}", max_norm=e1, row_relative=e2, prefix_rows_per_rank=pipe.prefix,
                     stage_entries=[st.nnz for st in pipe.stages], own_entries=pipe.own_nnz)
-            assert e1 < 2e-6 and e2 < TOL, (F, scheme, e1, e2)
+            assert e1 < 2e-6 and e2 < TOL, (F, tag, e1, e2)
             sg.drop_unused_pipelines()
         del x, xg, y, y_one
     for dd in sg.dirs:

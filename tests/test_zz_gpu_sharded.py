@@ -123,17 +123,22 @@ def test_two_gloo_ranks_on_one_gpu_pipelined_exchange_without_hubs(cuda, monkeyp
     and the W1 update in the backward pass."""
     monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
     monkeypatch.setenv("TGCN_PIPE_STAGES", "3")
+    monkeypatch.setenv("TGCN_PIPE_PREFIX", "2048")           # three unpacked ranges of the prefix + one packed stage
     run(2, ["powerlaw_big_allhubs", "wordoc_allhubs"], "gloo")
 
 
-@pytest.mark.parametrize("world,stages,scheme", [(2, "2", "slices"), (4, "3", "slices"), (3, "", "peer")])
-def test_rccl_ranks_sharing_one_gpu_pipelined_exchange(cuda, monkeypatch, world, stages, scheme):
+@pytest.mark.parametrize("world,stages,scheme,prefix", [(2, "2", "slices", "0"), (4, "3", "slices", "0"), (3, "", "peer", "0"),
+                                                        (2, "3", "slices", "4096"), (3, "2", "slices", "auto")])
+def test_rccl_ranks_sharing_one_gpu_pipelined_exchange(cuda, monkeypatch, world, stages, scheme, prefix):
     """The same over RCCL (ranks sharing cuda:0 over loopback sockets): K all_to_all_single calls with split sizes are
-    posted on the communicator's stream before the own-column block is launched, and every stage block waits for its own."""
+    posted on the communicator's stream before the own-column block is launched, and every stage block waits for its own.
+    With a prefix the first K stages send contiguous ranges of the operand unpacked (batched send / recv) and one packed
+    stage follows."""
     _rccl_ranks_can_share_the_gpu()
     monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
     monkeypatch.setenv("TGCN_PIPE_STAGES", stages)
     monkeypatch.setenv("TGCN_PIPE_SCHEME", scheme)
+    monkeypatch.setenv("TGCN_PIPE_PREFIX", prefix)
     run(world, ["powerlaw_big_allhubs"], "nccl")
 
 

@@ -6,8 +6,9 @@ halo_lists=True)`: no process group, no collectives) and times, at the hidden an
   * B_r as ONE operator on the gathered block (what the halo / collective forms launch after the whole gather), and the
     halo form's extra kernels (pack + scatter of the referenced rows);
   * the column blocks of `_Pipeline` -- own-column block + K stage blocks added with `tgcn_spmm_acc` -- for K = 1, 2, 4, 8
-    ("slices": 1 / K of every peer's rows per stage) and for the per-peer scheme (W - 1 stages), each block alone and the
-    whole sequence back to back.
+    ("slices": 1 / K of every peer's rows per stage), for the per-peer scheme (W - 1 stages) and with the UNPACKED prefix
+    (`prefix="auto"`: the degree-ordered slots nearly every peer reads travel as K contiguous ranges, nothing packed; one
+    packed stage for the rest), each block alone and the whole sequence back to back.
 
 With T_x the time one rank's halo rows need on the links, the pipelined step is about
     max(T_own, T_x / K) + sum_k max(T_block_k, T_x / K)   (stage k + 1 travels under block k)
@@ -71,11 +72,14 @@ for di, d in enumerate(sg.dirs[:1]):
         remote = d.need_cols[(d.need_cols // hp) != R]
         out["halo_pack_plus_scatter_ms"] = timed(lambda: (sg._rows_gather(x_local, d.send_slots),
                                                           sg._rows_scatter(xbuf, remote, recv)))
-        for label, K, scheme in [(f"slices{k}", int(k), "slices") for k in args.stages.split(",")] + [("peer", 0, "peer")]:
-            sg.set_pipeline(K, scheme)
+        variants = [(f"slices{k}", int(k), "slices", 0) for k in args.stages.split(",")] + [("peer", 0, "peer", 0)] + \
+            [(f"slices{k}+prefix", int(k), "slices", "auto") for k in args.stages.split(",")]
+        for label, K, scheme, prefix in variants:
+            sg.set_pipeline(K, scheme, prefix=prefix)
             pipe = sg._pipeline(d)
+            packed = [st for st in pipe.stages if st.span is None]
             bufs = [torch.randn(sum(st.recv_counts), F, device=dev) for st in pipe.stages]
-            packs = timed(lambda: [sg._rows_gather(x_local, st.send_slots) for st in pipe.stages])
+            packs = timed(lambda: [sg._rows_gather(x_local, st.send_slots) for st in packed])
             own = timed(lambda: pipe.own.spmm(x_local, bias))
             y = pipe.own.spmm(x_local, bias)
             blocks = [timed(lambda st=st, b=b: st.op.spmm(b, out=y, accumulate=True)) if st.op is not None else 0.0
@@ -88,14 +92,21 @@ for di, d in enumerate(sg.dirs[:1]):
                         st.op.spmm(b, out=yy, accumulate=True)
                 return yy
             seq = timed(whole)
-            Tx = out["T_x_ms_at_link_peak"]
-            rows_k = [sum(st.recv_counts) for st in pipe.stages]
-            pers = [Tx * rk / max(1, sum(rows_k)) for rk in rows_k]                  # a stage's share of the transfer
-            # stage 0 travels under the own block, stage k + 1 under block k; the last block has nothing left to hide
+            # transfer at link peak: the rows that ARRIVE from the other ranks (an unread prefix row travels too)
+            rows_k = [(W - 1) * (st.span[1] - st.span[0]) if st.span is not None else sum(st.recv_counts) for st in pipe.stages]
+            arriving = sum(rows_k)
+            Tx = arriving * F * 4 / ((W - 1) * link_GBps * 1e6)
+            pers = [Tx * rk / max(1, arriving) for rk in rows_k]                     # a stage's share of the transfer
+            # stage 0 travels under the own block (an unpacked one leaves at once, a packed one after its pack), stage k + 1
+            # under block k; the last block has nothing left to hide
             model = max(own, pers[0]) + sum(max(b, p_next) for b, p_next in zip(blocks[:-1], pers[1:])) + \
                 (blocks[-1] if blocks else 0.0)
-            out[label] = {"stages": len(pipe.stages), "own_nnz": pipe.own_nnz, "stage_nnz": [st.nnz for st in pipe.stages],
-                          "pack_ms": packs, "own_ms": own, "stage_block_ms": blocks, "sequence_ms": seq,
+            out[label] = {"stages": len(pipe.stages), "unpacked_stages": len(pipe.stages) - len(packed),
+                          "prefix_rows_per_rank": pipe.prefix, "own_nnz": pipe.own_nnz,
+                          "stage_nnz": [st.nnz for st in pipe.stages], "rows_arriving": arriving,
+                          "rows_read": sum(st.rows_read for st in pipe.stages),
+                          "transfer_ms_at_link_peak": round(Tx, 3), "pack_ms": packs, "own_ms": own,
+                          "stage_block_ms": blocks, "sequence_ms": seq, "compute_side_ms": round(packs + seq, 3),
                           "step_ms_model_at_link_peak": round(model + packs, 3)}
             sg.drop_unused_pipelines()
         out["halo_step_ms_model_at_link_peak"] = round(out["T_x_ms_at_link_peak"] + out["B_one_operator_ms"]
