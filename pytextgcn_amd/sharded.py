@@ -27,7 +27,9 @@ Graphs WITHOUT hub structure (`hubs=None`, BASELINE config c5) have no A_r whose
 default exchange is the PIPELINE (`_Pipeline`): B_r is cut by the origin of its columns into an own-column block, which
 starts at once on the rank's own rows, and K stage blocks; the referenced operand rows travel in K all-to-all stages
 (every link busy in every stage), and block k is ADDED to the result (`tgcn_spmm_acc`) as soon as stage k has landed --
-stage k + 1 is in flight under the compute of stage k ("run local part while halo is in flight").
+stage k + 1 is in flight under the compute of stage k ("run local part while halo is in flight").  Opt-in
+(`set_pipeline(prefix="auto")`): the rows of the first slots of every rank -- dealt in degree order, read by nearly every
+peer -- leave UNPACKED, as contiguous ranges of the operand; one packed stage carries the rest.
 
 Local layout on every rank: rows [0, hp) = own hub shard, rows [hp, hp + rp) = own regular shard
 (`owned` maps them to global node ids, -1 = padding row).

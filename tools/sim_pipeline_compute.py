@@ -73,7 +73,7 @@ for di, d in enumerate(sg.dirs[:1]):
         out["halo_pack_plus_scatter_ms"] = timed(lambda: (sg._rows_gather(x_local, d.send_slots),
                                                           sg._rows_scatter(xbuf, remote, recv)))
         variants = [(f"slices{k}", int(k), "slices", 0) for k in args.stages.split(",")] + [("peer", 0, "peer", 0)] + \
-            [(f"slices{k}+prefix", int(k), "slices", "auto") for k in args.stages.split(",")]
+            [(f"slices{k}+prefix", int(k), "slices", "auto") for k in args.stages.split(",") if int(k) > 1]
         for label, K, scheme, prefix in variants:
             sg.set_pipeline(K, scheme, prefix=prefix)
             pipe = sg._pipeline(d)
