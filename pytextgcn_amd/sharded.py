@@ -602,7 +602,8 @@ class ShardedGraph:
         # reduce-scatter starts when its rows are finished); bench.py times a few steps of each and keeps the fastest.
         #   "pipeline"    graphs without hub structure only (hubs=None; their DEFAULT): the halo rows travel in K stages and
         #                 the column block of stage k is added to the result while stage k + 1 is in flight (`_Pipeline`);
-        #                 TGCN_PIPE_STAGES / TGCN_PIPE_SCHEME pin K and the scheme (`set_pipeline`).
+        #                 TGCN_PIPE_STAGES / TGCN_PIPE_SCHEME pin K and the scheme, TGCN_PIPE_PREFIX = rows per rank (or
+        #                 "auto") that travel unpacked ahead of one packed stage (`set_pipeline`; default 0).
         import os
         self._build_halo_lists()
         self.set_rs_chunks(int(os.environ.get("TGCN_RS_CHUNKS", "1")))
