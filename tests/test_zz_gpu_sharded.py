@@ -103,6 +103,19 @@ def test_two_rccl_ranks_one_per_gpu(cuda, monkeypatch, exchange):
     run(2, ["wordoc_big", "wordoc_allhubs"], "nccl", device="cuda:{rank}")
 
 
+@pytest.mark.parametrize("prefix", ["0", "4096"])
+def test_two_rccl_ranks_one_per_gpu_pipelined_exchange(cuda, monkeypatch, prefix):
+    """The pipelined exchange of a hub-less graph with one rank per GPU (xGMI / PCIe P2P between two devices): packed
+    all-to-all stages, and with a prefix the unpacked ranges (batched send / recv of one source buffer).  Needs two GPUs;
+    the one-GPU test box skips it (its one-GPU form is test_rccl_ranks_sharing_one_gpu_pipelined_exchange)."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    monkeypatch.delenv("TGCN_EXCHANGE", raising=False)
+    monkeypatch.setenv("TGCN_PIPE_STAGES", "3")
+    monkeypatch.setenv("TGCN_PIPE_PREFIX", prefix)
+    run(2, ["powerlaw_big_allhubs"], "nccl", device="cuda:{rank}")
+
+
 @pytest.mark.parametrize("world,exchange,chunks", [(2, "collective", "1"), (2, "p2p", "1"), (2, "halo", "1"),
                                                    (2, "collective", "4"), (4, "collective", "2"), (3, "halo", "1")])
 def test_rccl_ranks_sharing_one_gpu(cuda, monkeypatch, world, exchange, chunks):
