@@ -1834,6 +1834,22 @@ def test_compute_entry_points_are_hipgraph_capturable(cuda):
     assert out.item() == loss_eager                             # deterministic kernels: bitwise
     assert torch.equal(w1.detach(), w1_eager) and torch.equal(w2.detach(), w2_eager)
     assert not torch.equal(w1.detach(), ref_w1)
+    # the accumulate form (tgcn_spmm_acc) only enqueues, too: captured and replayed, it adds the product once per replay
+    xs = torch.randn(N, F, device=cuda)
+    acc = torch.zeros(N, F, device=cuda)
+    plan.spmm(xs, out=acc.clone(), accumulate=True)             # (workspace of this stream / width exists before the capture)
+    side.wait_stream(torch.cuda.current_stream())
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        plan.spmm(xs, out=torch.zeros(N, F, device=cuda), accumulate=True)       # the side stream's own workspace
+        with torch.cuda.graph(g2, stream=side):
+            plan.spmm(xs, out=acc, accumulate=True)
+    torch.cuda.current_stream().wait_stream(side)
+    acc.zero_()
+    g2.replay(), g2.replay()
+    torch.cuda.synchronize()
+    once = plan.spmm(xs)
+    assert rel_err(acc, 2.0 * once.double()) < 1e-6
 
 
 def test_work_partition_stress_with_tiny_blocks(cuda, monkeypatch):
