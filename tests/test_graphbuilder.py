@@ -210,6 +210,13 @@ def test_gpu_builder_edge_cases_and_errors(cuda, counter):
     coo, w = compute_word_word_edges(X, 5, 4, 6, 3, counter=counter)
     assert coo.shape == (0, 2) and w.shape == (0,)
     assert sliding_window_tester(X, 5, 4, 6, 3, counter=counter).sum() == 0
+    coo, w = compute_word_word_edges(np.zeros((0, 6), dtype=np.int32), 5, 0, 6, 3, counter=counter)   # no documents at all
+    assert coo.shape == (0, 2) and w.shape == (0,)
+    one = np.full((3, 4), 2, dtype=np.int32)                    # one word only: diagonal counts, no pair, no edge
+    coo, w = compute_word_word_edges(one, 5, 3, 4, 9, counter=counter)                                 # window > seq_len
+    assert coo.shape == (0, 2)
+    c = sliding_window_tester(one, 5, 3, 4, 9, counter=counter)
+    assert int(c.sum()) == int(c[G._sym_diag_idx(2, 2, 5)] if hasattr(G, "_sym_diag_idx") else c.max()) == 3 * 10
     with pytest.raises(ValueError):
         compute_word_word_edges(X, 5, 4, 6, 3, counter="hashed")
     with pytest.raises(IndexError):
