@@ -4,7 +4,11 @@ Text2GraphTransformer -> Data -> GCN(graph) -> CE on train_mask -> Adam(amsgrad)
 the host), same hyper-parameter names, on a synthetic corpus because the Amazon / DBpedia CSVs are
 not in the reference tree (.MISSING_LARGE_BLOBS:1-3).  Line references: flat_amazon.py.
 
-    python examples/flat_synthetic.py [--docs 5000] [--epochs 50] [--fused]
+    python examples/flat_synthetic.py [--docs 5000] [--epochs 50] [--fused] [--preset amazon|dbpedia]
+
+`--preset dbpedia` takes flat_dbpedia.py's settings instead (flat_dbpedia.py:20-34,70-71,80: dropout 0.5, max_df 0.4, window 5,
+documents cut to 15 tokens, hidden width 32, a separate validation split appended to the training documents) with a class count
+that is not a multiple of 4 (DBpedia's l3 has 219: odd widths take the padded buffers and column-group products).
 """
 import argparse
 import os
@@ -23,27 +27,37 @@ p = argparse.ArgumentParser()
 p.add_argument("--docs", type=int, default=5000)
 p.add_argument("--epochs", type=int, default=50)
 p.add_argument("--fused", action="store_true", help="pytextgcn_amd.train.FlatLoop: the same epoch with every switch of the package instead of torch's CE / Adam / dropout")
+p.add_argument("--preset", choices=["amazon", "dbpedia"], default="amazon", help="hyper-parameters of flat_amazon.py or of flat_dbpedia.py")
 p.add_argument("--reorder", action="store_true",
                help="pytextgcn_amd.reorder_documents: lay the document nodes out by clusters found from the graph (a corpus "
                     "with topical locality whose file is not sorted by class gathers fewer distinct word rows per stretch)")
 args = p.parse_args()
 
-seed, lr, dropout, window_size, min_df = 44, 0.05, 0.7, 20, 5          # :22-35,66
+seed, lr, min_df = 44, 0.05, 5                                         # :22-35,66 (min_df 100 at DBpedia's 240 k documents)
+if args.preset == "amazon":
+    dropout, window_size, max_df, max_length, n_hidden, n_classes = 0.7, 20, 0.7, None, 100, 6
+else:                                                                  # flat_dbpedia.py:20-34,70-71,80
+    dropout, window_size, max_df, max_length, n_hidden, n_classes = 0.5, 5, 0.4, 15, 32, 19
 np.random.seed(seed)
 th.manual_seed(seed)
-docs, y = synth.synthetic_corpus(args.docs, 3000, n_classes=6, seed=seed)
-perm = np.random.permutation(len(docs))
-test_idx, val_idx = perm[:len(docs) // 10], perm[len(docs) // 10:len(docs) // 5]
+docs, y = synth.synthetic_corpus(args.docs, 3000, n_classes=n_classes, seed=seed)
+if args.preset == "amazon":
+    perm = np.random.permutation(len(docs))
+    test_idx, val_idx = perm[:len(docs) // 10], perm[len(docs) // 10:len(docs) // 5]
+else:                                       # flat_dbpedia.py:54-66: train, then the validation file, then the test file
+    n = len(docs)
+    val_idx, test_idx = np.arange(n - n // 5, n - n // 10), np.arange(n - n // 10, n)
 
 t0 = time.time()
-t2g = Text2GraphTransformer(n_jobs=8, min_df=min_df, window_size=window_size, rm_stopwords=False, verbose=1)
+t2g = Text2GraphTransformer(n_jobs=8, min_df=min_df, window_size=window_size, rm_stopwords=False, verbose=1, max_df=max_df,
+                            **({} if max_length is None else {"max_length": max_length}))
 g = t2g.fit_transform(docs, y, test_idx=test_idx, val_idx=val_idx)     # :66-70
 print(f"graph: {g}  ({time.time() - t0:.2f} s)")
 if args.reorder:
     from pytextgcn_amd import reorder_documents
     g, perm = reorder_documents(g)     # same graph, other numbering: the loop below addresses nodes through the masks only
 
-gcn = GCN(g.x.shape[1], len(np.unique(y)), n_hidden_gcn=100, dropout=dropout)   # :80
+gcn = GCN(g.x.shape[1], len(np.unique(y)), n_hidden_gcn=n_hidden, dropout=dropout)   # :80
 criterion = th.nn.CrossEntropyLoss(reduction="mean")                   # :82
 device = th.device("cuda")                                             # :84
 gcn = gcn.to(device).float()                                           # :85

@@ -49,6 +49,26 @@ def test_flat_script_trains_in_both_forms_and_they_agree(cuda):
     assert abs(accs["plain"] - accs["fused"]) <= 0.01 + 1e-9, accs
 
 
+def test_flat_script_with_the_dbpedia_settings(cuda):
+    """`flat_synthetic.py --preset dbpedia`: flat_dbpedia.py's hyper-parameters (window 5, documents cut to 15 tokens, max_df 0.4,
+    hidden width 32, dropout 0.5, validation documents appended behind the training documents) and 19 classes -- a class count
+    that is no multiple of 4, as DBpedia's 219 -- in both forms of the loop."""
+    accs = {}
+    for form in ([], ["--fused"]):
+        out = _run([sys.executable, os.path.join(ROOT, "examples", "flat_synthetic.py"), "--docs", "3000", "--epochs", "60",
+                    "--preset", "dbpedia"] + form)
+        rows = _epochs(out)
+        first, last = rows[0], rows[-1]
+        # (15-token documents, 19 classes: the network memorises the training rows -- the validation loss is reported every
+        # epoch, flat_dbpedia.py:110, but need not fall)
+        assert int(last[0]) == 60 and float(last[1]) < 0.2 * float(first[1]) and float(last[2]) > 0, (first, last)
+        assert float(last[3]) > 0.9 > float(first[3]), (first, last)
+        m = re.search(r"Test Accuracy:\s*([\d.]+)\s+F1-Macro:\s*([\d.]+)", out)
+        assert m, out[-800:]
+        accs["fused" if form else "plain"] = float(m.group(1))
+    assert min(accs.values()) > 0.25 and abs(accs["plain"] - accs["fused"]) <= 0.05, accs      # (chance: 1 / 19)
+
+
 def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
