@@ -4,8 +4,10 @@ set -u
 R=gpurun_out/knobs
 mkdir -p $R
 rc_all=0
+only=" $* "           # optional: names of the runs to do (default: all) -- a full matrix exceeds one 20-minute GPU call
 run() {
   name="$1"; shift
+  if [ "$only" != "  " ] && [[ "$only" != *" $name "* ]]; then return; fi
   env "$@" timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "not c5 and not hot_block and not c4" > $R/$name.log 2>&1
   rc=$?
   echo "$name rc=$rc $(tail -1 $R/$name.log)"
