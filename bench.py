@@ -1133,12 +1133,13 @@ def main():
                 candidates.append(("pipeline", 1, 0, "peer"))
             forms = forms + ["pipeline"]
         trial = {}
+        env_prefix = os.environ.get("TGCN_PIPE_PREFIX", "0")         # pinned by the caller: "auto" or rows per rank
+        env_prefix = "auto" if env_prefix == "auto" else (int(env_prefix) if env_prefix.isdigit() else 0)
         for mode, K, stages, scheme in candidates:
             if sg.rp > 0:
                 sg.set_rs_chunks(K)
             if mode == "pipeline":                               # ("auto": one all-reduce -- every rank is here)
-                sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else
-                                (int(os.environ["TGCN_PIPE_PREFIX"]) if os.environ.get("TGCN_PIPE_PREFIX", "").isdigit() else 0))
+                sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else env_prefix)
             sg.exchange = mode
             label = f"{mode}/{K}" if mode != "pipeline" else f"pipeline-{scheme}/{world - 1 if scheme == 'peer' else sg.pipe_stages}"
             # A form this backend / build refuses raises on every rank alike, before anything is enqueued, and is
@@ -1174,8 +1175,7 @@ def main():
         if sg.rp > 0:
             sg.set_rs_chunks(K)
         if mode == "pipeline":
-            sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else
-                            (int(os.environ["TGCN_PIPE_PREFIX"]) if os.environ.get("TGCN_PIPE_PREFIX", "").isdigit() else 0))
+            sg.set_pipeline(stages, scheme.split("+")[0], prefix="auto" if scheme.endswith("+prefix") else env_prefix)
         sg.exchange = mode
         sg.drop_unused_chunks()                    # the operators of the configurations that lost are dead weight
         sg.drop_unused_pipelines()
