@@ -352,6 +352,63 @@ def test_build_refuses_scratch_in_any_kernel_that_is_not_allow_listed():
             or "TGCN_NT_PIPE=0" in rep["sources"]["dense.hip"]["pipe_kernel_isa_check"]
 
 
+def test_build_does_not_ship_an_unverified_pipe_kernel(tmp_path, monkeypatch):
+    """when the disassembly scan of k_gemm_pipe cannot run (no llvm-objdump, no gfx950 bundle) the build must not
+    ship the kernel unchecked and must not stay silent: it warns, compiles dense.hip again with -DTGCN_NT_PIPE=0 and records
+    that in the build report.  The compiler is faked here (canned remarks, empty objects) and every path points into a
+    scratch directory: this tests the build's LOGIC, not hipcc."""
+    import subprocess
+    import warnings
+    from pytextgcn_amd import build
+
+    def remark(name):
+        return (f"dense.hip:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]\n"
+                "remark:     VGPRs: 200 [-R]\nremark:     ScratchSize [bytes/lane]: 0 [-R]\n"
+                "remark:     SGPRs Spill: 0 [-R]\nremark:     VGPRs Spill: 0 [-R]\n")
+    canned = remark("_ZN4tgcn12_GLOBAL__N_111k_gemm_pipeILi7ELi8ELb1ELb1ELb1EEEvPKf") + \
+        remark("_ZN4tgcn12_GLOBAL__N_111k_gemm_tallILi7ELb1ELb1ELi8ELb1ELb1EEEvPKf")
+    commands = []
+
+    class FakeProc:
+        returncode = 0
+
+        def __init__(self, cmd, **kw):
+            commands.append(cmd)
+            open(cmd[cmd.index("-o") + 1], "wb").close()
+
+        def communicate(self):
+            return canned, None
+
+    def fake_run(cmd, **kw):
+        commands.append(cmd)
+        open(cmd[cmd.index("-o") + 1], "wb").close()
+        return subprocess.CompletedProcess(cmd, 0, stdout=canned)
+    monkeypatch.setattr(build, "LIB_DIR", str(tmp_path))
+    monkeypatch.setattr(build, "OBJ_DIR", str(tmp_path / "obj"))
+    monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "libtgcn.so"))
+    monkeypatch.setattr(build, "REPORT_PATH", str(tmp_path / "build_report.json"))
+    monkeypatch.setattr(build, "SOURCES", ["dense.hip"])
+    monkeypatch.setattr(build.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(build.subprocess, "run", fake_run)
+    monkeypatch.setattr(build.shutil, "which", lambda name: "/bin/sh")           # (any existing path: it is never run)
+    monkeypatch.setattr(build, "check_pipe_kernel_isa", lambda obj: "k_gemm_pipe ISA check skipped: llvm-objdump not found")
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        build.build(force=True)
+    assert any("TGCN_NT_PIPE=0" in str(w.message) and "skipped" in str(w.message) for w in seen)
+    compiles = [c for c in commands if "-c" in c]
+    assert len(compiles) == 2 and "-DTGCN_NT_PIPE=0" not in compiles[0] and "-DTGCN_NT_PIPE=0" in compiles[1]
+    note = build.build_report()["sources"]["dense.hip"]["pipe_kernel_isa_check"]
+    assert "skipped" in note and note.endswith("built with -DTGCN_NT_PIPE=0")
+    # ... and a scan that runs and passes leaves one compile and no warning
+    commands.clear()
+    monkeypatch.setattr(build, "check_pipe_kernel_isa", lambda obj: "k_gemm_pipe ISA check: 4 instantiations, no instruction touches a ring register in flight")
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        build.build(force=True)
+    assert not seen and len([c for c in commands if "-c" in c]) == 1
+
+
 def test_build_refuses_a_touched_ring_register_of_the_block_pipelined_kernel():
     """k_gemm_pipe keeps inline-asm loads in flight across a whole k-loop; the build scans its disassembly
     (pytextgcn_amd/build.py: scan_pipe_isa / check_pipe_kernel_isa) and fails if ANY instruction names a destination
